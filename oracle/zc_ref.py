@@ -1,0 +1,259 @@
+"""
+ctypes loader for the CPU oracle (oracle/libzc_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by dusk_zerocaf_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libzc_ref.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "zc_ref.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libzc_ref.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _u64(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim == 2 and a.shape[1] == width, a.shape
+    return a
+
+
+def _u8(a, width=32):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2 and a.shape[1] == width, a.shape
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _binop(name, width):
+    def f(a, b):
+        a, b = _u64(a, width), _u64(b, width)
+        out = np.empty_like(a)
+        getattr(lib(), name)(_p(a), _p(b), _p(out), C.c_size_t(a.shape[0]))
+        return out
+    return f
+
+
+def _unop(name, width):
+    def f(a):
+        a = _u64(a, width)
+        out = np.empty_like(a)
+        getattr(lib(), name)(_p(a), _p(out), C.c_size_t(a.shape[0]))
+        return out
+    return f
+
+
+fe_add = _binop("zr_fe_add_batch", 5)
+fe_sub = _binop("zr_fe_sub_batch", 5)
+fe_mul = _binop("zr_fe_mul_batch", 5)
+fe_neg = _unop("zr_fe_neg_batch", 5)
+fe_square = _unop("zr_fe_square_batch", 5)
+sc_add = _binop("zr_sc_add_batch", 5)
+sc_sub = _binop("zr_sc_sub_batch", 5)
+sc_mul = _binop("zr_sc_mul_batch", 5)
+sc_neg = _unop("zr_sc_neg_batch", 5)
+sc_square = _unop("zr_sc_square_batch", 5)
+ed_add = _binop("zr_ed_add_batch", 20)
+ed_sub = _binop("zr_ed_sub_batch", 20)
+ed_double = _unop("zr_ed_double_batch", 20)
+ed_neg = _unop("zr_ed_neg_batch", 20)
+
+
+def fe_invert(a):
+    a = _u64(a, 5)
+    out = np.empty_like(a)
+    ok = np.empty(a.shape[0], dtype=np.uint8)
+    lib().zr_fe_invert_batch(_p(a), _p(out), _p(ok), C.c_size_t(a.shape[0]))
+    return out, ok
+
+
+def fe_from_bytes(b):
+    b = _u8(b)
+    out = np.empty((b.shape[0], 5), dtype=np.uint64)
+    lib().zr_fe_from_bytes_batch(_p(b), _p(out), C.c_size_t(b.shape[0]))
+    return out
+
+
+def fe_to_bytes(a):
+    a = _u64(a, 5)
+    out = np.empty((a.shape[0], 32), dtype=np.uint8)
+    lib().zr_fe_to_bytes_batch(_p(a), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
+def fe_sqrt_ratio_i(u, v):
+    u, v = _u64(u, 5), _u64(v, 5)
+    out = np.empty_like(u)
+    sq = np.empty(u.shape[0], dtype=np.uint8)
+    lib().zr_fe_sqrt_ratio_i_batch(_p(u), _p(v), _p(out), _p(sq), C.c_size_t(u.shape[0]))
+    return out, sq
+
+
+def sc_from_bytes(b):
+    b = _u8(b)
+    out = np.empty((b.shape[0], 5), dtype=np.uint64)
+    ok = np.empty(b.shape[0], dtype=np.uint8)
+    lib().zr_sc_from_bytes_batch(_p(b), _p(out), _p(ok), C.c_size_t(b.shape[0]))
+    return out, ok
+
+
+def sc_to_bytes(a):
+    a = _u64(a, 5)
+    out = np.empty((a.shape[0], 32), dtype=np.uint8)
+    lib().zr_sc_to_bytes_batch(_p(a), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
+def ed_scalar_mul(p, k):
+    p, k = _u64(p, 20), _u64(k, 5)
+    assert p.shape[0] == k.shape[0]
+    out = np.empty_like(p)
+    lib().zr_ed_scalar_mul_batch(_p(p), _p(k), _p(out), C.c_size_t(p.shape[0]))
+    return out
+
+
+def ed_mul_by_pow_2(p, kexp):
+    p = _u64(p, 20)
+    out = np.empty_like(p)
+    lib().zr_ed_mul_by_pow_2_batch(_p(p), C.c_uint64(kexp), _p(out), C.c_size_t(p.shape[0]))
+    return out
+
+
+def ed_to_affine(p):
+    p = _u64(p, 20)
+    xy = np.empty((p.shape[0], 10), dtype=np.uint64)
+    ok = np.empty(p.shape[0], dtype=np.uint8)
+    lib().zr_ed_to_affine_batch(_p(p), _p(xy), _p(ok), C.c_size_t(p.shape[0]))
+    return xy, ok
+
+
+def ed_eq(p, q):
+    p, q = _u64(p, 20), _u64(q, 20)
+    eq = np.empty(p.shape[0], dtype=np.uint8)
+    lib().zr_ed_eq_batch(_p(p), _p(q), _p(eq), C.c_size_t(p.shape[0]))
+    return eq
+
+
+def ed_compress(p):
+    p = _u64(p, 20)
+    out = np.empty((p.shape[0], 32), dtype=np.uint8)
+    ok = np.empty(p.shape[0], dtype=np.uint8)
+    lib().zr_ed_compress_batch(_p(p), _p(out), _p(ok), C.c_size_t(p.shape[0]))
+    return out, ok
+
+
+def ed_decompress(b):
+    b = _u8(b)
+    out = np.empty((b.shape[0], 20), dtype=np.uint64)
+    ok = np.empty(b.shape[0], dtype=np.uint8)
+    lib().zr_ed_decompress_batch(_p(b), _p(out), _p(ok), C.c_size_t(b.shape[0]))
+    return out, ok
+
+
+def ris_compress(p):
+    p = _u64(p, 20)
+    out = np.empty((p.shape[0], 32), dtype=np.uint8)
+    lib().zr_ris_compress_batch(_p(p), _p(out), C.c_size_t(p.shape[0]))
+    return out
+
+
+def ris_decompress(b):
+    b = _u8(b)
+    out = np.empty((b.shape[0], 20), dtype=np.uint64)
+    ok = np.empty(b.shape[0], dtype=np.uint8)
+    lib().zr_ris_decompress_batch(_p(b), _p(out), _p(ok), C.c_size_t(b.shape[0]))
+    return out, ok
+
+
+def ris_eq(p, q):
+    p, q = _u64(p, 20), _u64(q, 20)
+    eq = np.empty(p.shape[0], dtype=np.uint8)
+    lib().zr_ris_eq_batch(_p(p), _p(q), _p(eq), C.c_size_t(p.shape[0]))
+    return eq
+
+
+def ris_roundtrip_mul(b, k):
+    b, k = _u8(b), _u64(k, 5)
+    out = np.empty_like(b)
+    ok = np.empty(b.shape[0], dtype=np.uint8)
+    lib().zr_ris_roundtrip_mul_batch(_p(b), _p(k), _p(out), _p(ok), C.c_size_t(b.shape[0]))
+    return out, ok
+
+
+def msm_naive(p, k):
+    p, k = _u64(p, 20), _u64(k, 5)
+    out = np.empty((1, 20), dtype=np.uint64)
+    lib().zr_msm_naive(_p(p), _p(k), C.c_size_t(p.shape[0]), _p(out))
+    return out
+
+
+# ---- single-element helpers used by the KAT tests (lists of python ints) ----
+class _FE(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 5)]
+
+
+class _PT(C.Structure):
+    _fields_ = [("X", _FE), ("Y", _FE), ("Z", _FE), ("T", _FE)]
+
+
+def _fe(l):
+    return _FE((C.c_uint64 * 5)(*[int(x) for x in l]))
+
+
+def _pt(p):
+    return _PT(*[_fe(c) for c in p])
+
+
+def _fl(f):
+    return [int(x) for x in f.l]
+
+
+def _pl(p):
+    return [_fl(p.X), _fl(p.Y), _fl(p.Z), _fl(p.T)]
+
+
+def call_fe(name, *args):
+    """r = name(fe args...) for functions of the form void f(zr_fe *r, const zr_fe*...)."""
+    r = _FE()
+    rc = getattr(lib(), name)(C.byref(r), *[C.byref(_fe(a)) if isinstance(a, (list, tuple)) else a for a in args])
+    return _fl(r), rc
+
+
+def call_pt(name, *args):
+    r = _PT()
+    conv = []
+    for a in args:
+        if isinstance(a, (list, tuple)) and len(a) == 4 and isinstance(a[0], (list, tuple)):
+            conv.append(C.byref(_pt(a)))
+        elif isinstance(a, (list, tuple)):
+            conv.append(C.byref(_fe(a)))
+        else:
+            conv.append(a)
+    rc = getattr(lib(), name)(C.byref(r), *conv)
+    return _pl(r), rc

@@ -1,0 +1,504 @@
+"""
+Pin the CPU oracle (oracle/zc_ref.c) and the independent big-int model
+(oracle/pymodel.py) against every known-answer vector of the reference's own
+unit tests for the hot path.  Each test names the reference test it mirrors.
+CPU only (no `gpu` marker).
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pymodel as pm
+
+ZERO = [0, 0, 0, 0, 0]
+ONE = [1, 0, 0, 0, 0]
+TWO = [2, 0, 0, 0, 0]
+
+
+def fe(kats, name):
+    return kats["field"][name]["limbs"]
+
+
+def sc(kats, name):
+    return kats["scalar"][name]["limbs"]
+
+
+def cst(kats, name):
+    return kats["constants"][name]["limbs"]
+
+
+def ept(kats, name):
+    c = kats["edwards_points"][name]["coords"]
+    return [c["X"], c["Y"], c.get("Z", ONE), c.get("T", ZERO)]
+
+
+MINUS_ONE = [671914833335276, 3916664325105025, 1367801, 0, 17592186044416]  # field.rs:523-531
+SC_MINUS_ONE = [1129677152307298, 1363544697812651, 714439, 0, 2199023255552]  # scalar.rs:341-343
+
+
+# ------------------------------------------------------------------ constants sanity
+def test_constants_match_model(kats):
+    assert pm.from_limbs(cst(kats, "FIELD_L")) == pm.P
+    assert pm.from_limbs(cst(kats, "L")) == pm.L
+    assert pm.from_limbs(cst(kats, "EDWARDS_D")) == pm.D
+    assert pm.from_limbs(cst(kats, "EDWARDS_A")) == pm.A
+    assert pm.from_limbs(cst(kats, "SQRT_MINUS_ONE")) == pm.SQRT_M1
+    assert pm.from_limbs(cst(kats, "INV_SQRT_A_MINUS_D")) == pm.INV_SQRT_A_MINUS_D
+    assert pm.from_limbs(cst(kats, "RR_FIELD")) == pow(2, 520, pm.P)
+    assert pm.from_limbs(cst(kats, "RR")) == pow(2, 520, pm.L)
+    assert pm.from_limbs(cst(kats, "POS_RANGE")) == (pm.P - 1) // 2
+    assert pm.from_limbs(cst(kats, "INVERSE_MOD_TWO")) == (pm.P + 1) // 2
+    assert pm.from_limbs(cst(kats, "SCALAR_INVERSE_MOD_TWO")) == (pm.L + 1) // 2
+    bp = kats["constants_points"]["BASEPOINT"]["coords"]
+    assert tuple(pm.from_limbs(bp[c]) for c in "XYZT") == pm.BASEPOINT
+    # constants.rs:18,59 (-1/L mod 2^52)
+    assert (-pow(pm.L, -1, 2**52)) % 2**52 == 1331240223835829
+    assert (-pow(pm.P, -1, 2**52)) % 2**52 == 1439961107955227
+
+
+def test_oracle_exports_same_constants(oracle, kats):
+    lib = oracle.lib()
+    for cname, key in [("ZR_FIELD_L", "FIELD_L"), ("ZR_RR_FIELD", "RR_FIELD"), ("ZR_EDWARDS_D", "EDWARDS_D"),
+                       ("ZR_EDWARDS_A", "EDWARDS_A"), ("ZR_SQRT_MINUS_ONE", "SQRT_MINUS_ONE"),
+                       ("ZR_INV_SQRT_A_MINUS_D", "INV_SQRT_A_MINUS_D"), ("ZR_SQRT_AD_MINUS_ONE", "SQRT_AD_MINUS_ONE"),
+                       ("ZR_POS_RANGE", "POS_RANGE"), ("ZR_INVERSE_MOD_TWO", "INVERSE_MOD_TWO"),
+                       ("ZR_MINUS_ONE_HALF", "MINUS_ONE_HALF"), ("ZR_L", "L"), ("ZR_RR", "RR"),
+                       ("ZR_SCALAR_INVERSE_MOD_TWO", "SCALAR_INVERSE_MOD_TWO")]:
+        v = (C.c_uint64 * 5).in_dll(lib, cname)
+        assert list(v) == cst(kats, key), cname
+
+
+# ------------------------------------------------------------------ field.rs tests (:1136-1555)
+def test_field_addition(oracle, kats):
+    # addition_with_modulo / addition_mod_0 / addition_without_modulo / add_field_l
+    assert oracle.call_fe("zr_fe_add", MINUS_ONE, ONE)[0] == ZERO
+    assert oracle.call_fe("zr_fe_add", fe(kats, "A"), fe(kats, "B"))[0] == fe(kats, "A_PLUS_B")
+    assert oracle.call_fe("zr_fe_add", TWO, cst(kats, "FIELD_L"))[0] == TWO
+
+
+def test_field_subtraction(oracle, kats):
+    assert oracle.call_fe("zr_fe_sub", fe(kats, "A"), fe(kats, "B"))[0] == fe(kats, "A_MINUS_B")
+    assert oracle.call_fe("zr_fe_sub", fe(kats, "B"), fe(kats, "A"))[0] == fe(kats, "B_MINUS_A")
+    assert oracle.call_fe("zr_fe_sub", fe(kats, "B"), fe(kats, "B"))[0] == ZERO
+    assert oracle.call_fe("zr_fe_sub", TWO, cst(kats, "FIELD_L"))[0] == TWO
+
+
+def test_field_mul_square(oracle, kats):
+    assert oracle.call_fe("zr_fe_mul", fe(kats, "A"), fe(kats, "B"))[0] == fe(kats, "A_TIMES_B")
+    assert oracle.call_fe("zr_fe_mul", fe(kats, "A"), fe(kats, "C"))[0] == fe(kats, "A_TIMES_C")
+    assert oracle.call_fe("zr_fe_square", fe(kats, "A"))[0] == fe(kats, "A_SQUARE")
+    assert oracle.call_fe("zr_fe_square", fe(kats, "B"))[0] == fe(kats, "B_SQUARE")
+    assert oracle.call_fe("zr_fe_square", ZERO)[0] == ZERO
+    assert oracle.call_fe("zr_fe_square", ONE)[0] == ONE
+
+
+def test_field_division(oracle, kats):
+    a, b, expected = [x["limbs"] for x in kats["field_division"]]
+    na = oracle.call_fe("zr_fe_neg", a)[0]
+    r, rc = oracle.call_fe("zr_fe_div", na, b)
+    assert rc == 1 and r == expected
+    assert oracle.call_fe("zr_fe_div", a, ZERO)[1] == 0  # reference: assert!/panic
+    # doc-test src/field.rs:51: -126296/126297 == EDWARDS_D
+    n = oracle.call_fe("zr_fe_neg", [126296, 0, 0, 0, 0])[0]
+    assert oracle.call_fe("zr_fe_div", n, [126297, 0, 0, 0, 0])[0] == cst(kats, "EDWARDS_D")
+
+
+def test_field_pow_legendre(oracle, kats):
+    assert oracle.call_fe("zr_fe_pow", fe(kats, "A"), fe(kats, "C"))[0] == fe(kats, "A_POW_C")
+    assert oracle.call_fe("zr_fe_pow", fe(kats, "A"), fe(kats, "B"))[0] == fe(kats, "A_POW_B")
+    lib = oracle.lib()
+    assert lib.zr_fe_legendre_symbol(C.byref(oracle._fe(fe(kats, "A")))) == 0
+    assert lib.zr_fe_legendre_symbol(C.byref(oracle._fe([17, 0, 0, 0, 0]))) == 1
+
+
+def test_field_mod_sqrt(oracle, kats):
+    seventeen = [17, 0, 0, 0, 0]
+    r, rc = oracle.call_fe("zr_fe_mod_sqrt", seventeen, 0)
+    assert rc == 1 and r == fe(kats, "SQRT1_27_NEG")
+    r, rc = oracle.call_fe("zr_fe_mod_sqrt", seventeen, 1)
+    assert rc == 1 and r == fe(kats, "SQRT1_27_POS")
+    for s in (0, 1):
+        r, rc = oracle.call_fe("zr_fe_mod_sqrt", ZERO, s)
+        assert rc == 1 and r == ZERO
+        assert oracle.call_fe("zr_fe_mod_sqrt", fe(kats, "A"), s)[1] == 0  # non-QR -> None
+    # same through the independent model
+    assert pm.limbs(pm.mod_sqrt(17, 0)) == fe(kats, "SQRT1_27_NEG")
+    assert pm.limbs(pm.mod_sqrt(17, 1)) == fe(kats, "SQRT1_27_POS")
+
+
+def test_field_inv_sqrt(oracle, kats):
+    r, _ = oracle.call_fe("zr_fe_inv_sqrt", [27, 0, 0, 0, 0])
+    assert oracle.call_fe("zr_fe_neg", r)[0] == fe(kats, "INV_SQRT_27")
+    assert pm.limbs((-pm.inv_sqrt(27)[1]) % pm.P) == fe(kats, "INV_SQRT_27")
+
+
+def test_field_bytes(oracle, kats):
+    mb = kats["field_bytes"]["MINUS_ONE_BYTES"]["bytes"]
+    assert oracle.fe_from_bytes(np.array([mb], dtype=np.uint8))[0].tolist() == MINUS_ONE
+    assert oracle.fe_to_bytes(np.array([MINUS_ONE], dtype=np.uint64))[0].tolist() == mb
+    # from_ristretto255scalar / into_ristretto255scalar (field.rs:1379-1422): bytes <-> limbs
+    dalek_bytes = bytes.fromhex("4e5ab4345d4708845913b4641bc27d5252a585101bcc4244d449f4a879d9f204")
+    want = kats["field_dalek"][0]["limbs"]
+    assert oracle.fe_from_bytes(np.frombuffer(dalek_bytes, dtype=np.uint8).reshape(1, 32))[0].tolist() == want
+    assert bytes(oracle.fe_to_bytes(np.array([want], dtype=np.uint64))[0].tolist()) == dalek_bytes
+    assert pm.limbs(pm.fe_from_bytes(dalek_bytes)) == want
+    # l_field_high_bit
+    assert oracle.fe_to_bytes(np.array([cst(kats, "FIELD_L")], dtype=np.uint64))[0][31] < 128
+
+
+def test_field_two_pow_k_half_ord(oracle, kats):
+    assert oracle.call_fe("zr_fe_two_pow_k", C.c_uint64(0))[0] == ONE
+    assert oracle.call_fe("zr_fe_two_pow_k", C.c_uint64(252))[0] == fe(kats, "TWO_POW_252")
+    assert oracle.call_fe("zr_fe_two_pow_k", C.c_uint64(197))[0] == fe(kats, "TWO_POW_197")
+    assert oracle.call_fe("zr_fe_two_pow_k", C.c_uint64(104))[0] == fe(kats, "TWO_POW_104")
+    assert oracle.call_fe("zr_fe_two_pow_k", C.c_uint64(253))[1] == 0
+    assert oracle.call_fe("zr_fe_half_without_mod", [0, 1, 0, 0, 0])[0] == [2251799813685248, 0, 0, 0, 0]
+    assert oracle.call_fe("zr_fe_half_without_mod", fe(kats, "A_MINUS_B"))[0] == fe(kats, "A_MINUS_B_HALF")
+    lib = oracle.lib()
+    cmpf = lambda a, b: lib.zr_fe_cmp(C.byref(oracle._fe(a)), C.byref(oracle._fe(b)))
+    assert cmpf([2, 0, 0, 0, 0], [0, 2, 0, 0, 0]) < 0
+    assert cmpf([0, 0, 0, 0, 1], [0, 2498436546, 6587652167965486, 0, 0]) > 0
+    assert cmpf([0, 1, 2, 3, 4], [0, 1, 2, 3, 4]) == 0
+    assert lib.zr_fe_is_even(C.byref(oracle._fe(fe(kats, "A")))) == 1
+    assert lib.zr_fe_is_even(C.byref(oracle._fe(fe(kats, "B")))) == 0
+
+
+def test_field_montgomery_neg_inverse(oracle, kats):
+    assert oracle.call_fe("zr_fe_to_montgomery", fe(kats, "A"))[0] == fe(kats, "INV_MONT_A")
+    assert oracle.call_fe("zr_fe_from_montgomery", fe(kats, "INV_MONT_A"))[0] == fe(kats, "A")
+    assert oracle.call_fe("zr_fe_neg", fe(kats, "A"))[0] == fe(kats, "MINUS_A")
+    assert oracle.call_fe("zr_fe_neg", fe(kats, "B"))[0] == fe(kats, "MINUS_B")
+    assert oracle.call_fe("zr_fe_neg", ONE)[0] == MINUS_ONE
+    assert oracle.call_fe("zr_fe_neg", MINUS_ONE)[0] == ONE
+    assert oracle.call_fe("zr_fe_neg", ZERO)[0] == ZERO
+    for n in "ABC":
+        r, rc = oracle.call_fe("zr_fe_inverse", fe(kats, n))
+        assert rc == 1 and r == fe(kats, "INV_MOD_" + n)
+        assert pm.limbs(pow(pm.from_limbs(fe(kats, n)), -1, pm.P)) == fe(kats, "INV_MOD_" + n)
+    assert oracle.call_fe("zr_fe_inverse", ZERO)[1] == 0
+
+
+# ------------------------------------------------------------------ scalar.rs tests (:788-1052)
+def test_scalar_add_sub(oracle, kats):
+    assert oracle.call_fe("zr_sc_add", sc(kats, "AB"), sc(kats, "BA"))[0] == ZERO
+    assert oracle.call_fe("zr_sc_add", sc(kats, "BA"), sc(kats, "A"))[0] == sc(kats, "B")
+    assert oracle.call_fe("zr_sc_sub", sc(kats, "A"), sc(kats, "B"))[0] == sc(kats, "AB")
+    assert oracle.call_fe("zr_sc_sub", sc(kats, "B"), sc(kats, "A"))[0] == sc(kats, "BA")
+
+
+def test_scalar_montgomery_mul_square(oracle, kats):
+    assert oracle.call_fe("zr_sc_to_montgomery", sc(kats, "A"))[0] == sc(kats, "A_MONT")
+    assert oracle.call_fe("zr_sc_from_montgomery", sc(kats, "Y_MONT"))[0] == sc(kats, "Y")
+    assert oracle.call_fe("zr_sc_mul", sc(kats, "X"), sc(kats, "Y"))[0] == sc(kats, "X_TIMES_Y")
+    assert oracle.call_fe("zr_sc_mul", sc(kats, "Y"), ONE)[0] == sc(kats, "Y")
+    assert oracle.call_fe("zr_sc_mul", sc(kats, "Y"), ZERO)[0] == ZERO
+    assert oracle.call_fe("zr_sc_montgomery_mul", sc(kats, "X"), sc(kats, "Y"))[0] == sc(kats, "X_TIMES_Y_MONT")
+    assert oracle.call_fe("zr_sc_square", sc(kats, "Y"))[0] == sc(kats, "Y_SQ")
+    assert oracle.call_fe("zr_sc_square", ZERO)[0] == ZERO
+    assert oracle.call_fe("zr_sc_square", ONE)[0] == ONE
+    # the model agrees on the same vectors (X = 2^250 - 1 is deliberately > L)
+    x, y = pm.from_limbs(sc(kats, "X")), pm.from_limbs(sc(kats, "Y"))
+    assert pm.limbs(x * y % pm.L) == sc(kats, "X_TIMES_Y")
+    assert pm.limbs(x * y * pow(2, -260, pm.L) % pm.L) == sc(kats, "X_TIMES_Y_MONT")
+
+
+def test_scalar_half_pow_twopow_shr(oracle, kats):
+    assert oracle.call_fe("zr_sc_half", sc(kats, "Y"))[0] == sc(kats, "Y_HALF")
+    a_half = oracle.call_fe("zr_sc_half", sc(kats, "A"))[0]
+    assert a_half == [0, 0, 0, 1, 0]
+    assert oracle.call_fe("zr_sc_half", a_half)[0] == [0, 0, 2251799813685248, 0, 0]
+    assert oracle.call_fe("zr_sc_pow", sc(kats, "A"), sc(kats, "B"))[0] == sc(kats, "A_POW_B")
+    assert oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(0))[0] == ONE
+    assert oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(1))[0] == TWO
+    assert oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(249))[0] == [0, 0, 0, 0, 2199023255552]
+    assert oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(248))[0] == [0, 0, 0, 0, 1099511627776]
+    assert oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(250))[1] == 0
+    assert oracle.call_fe("zr_sc_shr", sc(kats, "A"), C.c_uint(1))[0] == [0, 0, 0, 1, 0]
+    assert oracle.call_fe("zr_sc_shr", [0, 0, 0, 1, 0], C.c_uint(1))[0] == [0, 0, 2251799813685248, 0, 0]
+    assert oracle.call_fe("zr_sc_shr", ONE, C.c_uint(1))[0] == ZERO
+    assert oracle.call_fe("zr_sc_shr", SC_MINUS_ONE, C.c_uint(250))[0] == ZERO
+    assert oracle.call_fe("zr_sc_shr", [0, 0, 0, 0, 2199023255552], C.c_uint(248))[0] == TWO
+    assert oracle.call_fe("zr_sc_shr", [0, 0, 0, 0, 2199023255552], C.c_uint(249))[0] == ONE
+
+
+def test_scalar_bits_naf(oracle):
+    lib = oracle.lib()
+
+    def bits(l):
+        out = (C.c_uint8 * 256)()
+        lib.zr_sc_into_bits(out, C.byref(oracle._fe(l)))
+        return list(out)
+
+    assert bits(ZERO) == [0] * 256
+    assert bits(ONE) == [1] + [0] * 255
+    nine = [0] * 256
+    nine[0] = nine[3] = 1
+    assert bits([9, 0, 0, 0, 0]) == nine
+    t = [0] * 256
+    t[249] = 1
+    assert bits([0, 0, 0, 0, 2199023255552]) == t
+    lm1 = pm.L - 1
+    assert bits(SC_MINUS_ONE) == [(lm1 >> i) & 1 for i in range(256)]
+
+    def naf(l, w=None):
+        out = (C.c_int8 * 256)()
+        if w is None:
+            lib.zr_sc_compute_naf(out, C.byref(oracle._fe(l)))
+        else:
+            lib.zr_sc_compute_window_naf(out, C.byref(oracle._fe(l)), C.c_uint(w))
+        return list(out)
+
+    assert naf([7, 0, 0, 0, 0])[:4] == [-1, 0, 0, 1]  # scalar.rs:1024-1026
+    s = [1122334455, 0, 0, 0, 0]                       # scalar.rs:1031-1050
+    assert naf(s, 2)[:31] == [-1, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, -1, 0, 0, 0, -1, 0, -1, 0, 1, 0, -1, 0, 0, -1, 0, 1, 0, 0, 0, 1]
+    assert naf(s, 3)[:31] == [-1, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, -1, 0, 0, 0, 3, 0, 0, 1, 0, 0, -1, 0, 0, 3, 0, 0, 0, 0, 0, 1]
+    assert naf(s, 4)[:31] == [7, 0, 0, 0, -1, 0, 0, 0, 7, 0, 0, 0, 7, 0, 0, 0, 5, 0, 0, 0, 0, 7, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    assert naf(s, 5)[:32] == [-9, 0, 0, 0, 0, 0, 0, 0, -9, 0, 0, 0, 0, 0, 0, 11, 0, 0, 0, 0, 0, -9, 0, 0, 0, 0, -15, 0, 0, 0, 0, 1]
+    assert naf(s, 6)[:31] == [-9, 0, 0, 0, 0, 0, 0, 0, -9, 0, 0, 0, 0, 0, 0, 11, 0, 0, 0, 0, 0, 23, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+
+
+def test_scalar_from_bytes_range(oracle):
+    ok_b = (pm.L - 1).to_bytes(32, "little")
+    bad_b = pm.L.to_bytes(32, "little")
+    out, ok = oracle.sc_from_bytes(np.frombuffer(ok_b + bad_b, dtype=np.uint8).reshape(2, 32))
+    assert ok.tolist() == [1, 0]
+    assert out[0].tolist() == SC_MINUS_ONE
+    assert bytes(oracle.sc_to_bytes(out[:1])[0].tolist()) == ok_b
+
+
+# ------------------------------------------------------------------ edwards.rs tests (:1357-1617)
+def test_edwards_add_limb_exact(oracle, kats):
+    # extended_point_addition: P4_EXTENDED is the limb-exact output of the HWCD add
+    r, _ = oracle.call_pt("zr_ed_add", ept(kats, "P1_EXTENDED"), ept(kats, "P2_EXTENDED"))
+    assert r == ept(kats, "P4_EXTENDED")
+    m = pm.ed_add(tuple(map(pm.from_limbs, ept(kats, "P1_EXTENDED"))), tuple(map(pm.from_limbs, ept(kats, "P2_EXTENDED"))))
+    assert pm.pt_limbs(m) == ept(kats, "P4_EXTENDED")
+
+
+def test_edwards_double_neg_eq(oracle, kats):
+    lib = oracle.lib()
+    eq = lambda a, b: lib.zr_ed_eq(C.byref(oracle._pt(a)), C.byref(oracle._pt(b)))
+    p1, p3 = ept(kats, "P1_EXTENDED"), ept(kats, "P3_EXTENDED")
+    assert eq(oracle.call_pt("zr_ed_add", p1, p1)[0], p3) == 1
+    assert eq(oracle.call_pt("zr_ed_double", p1)[0], p3) == 1
+    ident = [ZERO, ONE, ONE, ZERO]
+    assert eq(oracle.call_pt("zr_ed_double", ident)[0], ident) == 1
+    assert eq(oracle.call_pt("zr_ed_neg", ident)[0], ident) == 1
+    assert eq(p1, ept(kats, "P2_EXTENDED")) == 0
+    # extended_double_and_add: P*8 == P.double().double().double(); doc-test edwards.rs:54-57
+    d = p1
+    for _ in range(3):
+        d = oracle.call_pt("zr_ed_double", d)[0]
+    assert eq(oracle.call_pt("zr_ed_scalar_mul", p1, [8, 0, 0, 0, 0])[0], d) == 1
+    assert eq(oracle.call_pt("zr_ed_mul_by_cofactor", p1)[0], d) == 1
+    # validity_check
+    for name in ("P1_EXTENDED", "P2_EXTENDED", "P4_EXTENDED"):
+        assert lib.zr_ed_is_valid(C.byref(oracle._pt(ept(kats, name)))) == 1
+    assert lib.zr_ed_is_valid(C.byref(oracle._pt(ident))) == 1
+
+
+def test_edwards_point_generation_and_codec(oracle, kats):
+    lib = oracle.lib()
+    eq = lambda a, b: lib.zr_ed_eq(C.byref(oracle._pt(a)), C.byref(oracle._pt(b)))
+    for n in ("P1", "P2"):
+        ext = ept(kats, n + "_EXTENDED")
+        r, rc = oracle.call_pt("zr_ed_new_from_y_coord", ext[1], 0)
+        assert rc == 1 and eq(r, ext) == 1
+        comp = kats["edwards_compressed"][n + "_COMPRESSED"]["bytes"]
+        out, ok = oracle.ed_compress(np.array([sum(ext, [])], dtype=np.uint64))
+        assert ok[0] == 1 and out[0].tolist() == comp
+        dec, ok = oracle.ed_decompress(np.array([comp], dtype=np.uint8))
+        assert ok[0] == 1 and eq([dec[0][i * 5:(i + 1) * 5].tolist() for i in range(4)], ext) == 1
+        assert list(pm.ed_compress(tuple(map(pm.from_limbs, ext)))) == comp
+    assert oracle.call_pt("zr_ed_new_from_y_coord", [15, 0, 0, 0, 0], 0)[1] == 0
+    fail = kats["edwards_inline_bytes"][2]["bytes"]
+    assert oracle.ed_decompress(np.array([fail], dtype=np.uint8))[1][0] == 0
+    # BASEPOINT_COMPRESSED (src/constants.rs:13-16)
+    bpc = kats["top_constants_bytes"]["BASEPOINT_COMPRESSED"]["bytes"]
+    bp = kats["constants_points"]["BASEPOINT"]["coords"]
+    bpl = [bp[c] for c in "XYZT"]
+    assert oracle.ed_compress(np.array([sum(bpl, [])], dtype=np.uint64))[0][0].tolist() == bpc
+
+
+def test_edwards_basepoint_order_and_mul_variants(oracle, kats):
+    lib = oracle.lib()
+    eq = lambda a, b: lib.zr_ed_eq(C.byref(oracle._pt(a)), C.byref(oracle._pt(b)))
+    ident = [ZERO, ONE, ONE, ZERO]
+    # unique_basepoint_test: y = 3/5, B*L == identity
+    y, _ = oracle.call_fe("zr_fe_div", [3, 0, 0, 0, 0], [5, 0, 0, 0, 0])
+    b, rc = oracle.call_pt("zr_ed_new_from_y_coord", y, 0)
+    bp = kats["constants_points"]["BASEPOINT"]["coords"]
+    assert rc == 1 and b == [bp[c] for c in "XYZT"]
+    assert eq(oracle.call_pt("zr_ed_scalar_mul", b, cst(kats, "L"))[0], ident) == 1
+    # left_to_right_bin_mul / naf_bin_mul
+    p1 = ept(kats, "P1_EXTENDED")
+    k215 = oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(215))[0]
+    k7 = oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(7))[0]
+    k249m1 = oracle.call_fe("zr_sc_sub", oracle.call_fe("zr_sc_two_pow_k", C.c_uint64(249))[0], ONE)[0]
+    assert eq(oracle.call_pt("zr_ed_scalar_mul", p1, k215)[0], oracle.call_pt("zr_ed_ltr_bin_mul", p1, k215)[0]) == 1
+    for k in (k7, k215, k249m1, SC_MINUS_ONE):
+        assert eq(oracle.call_pt("zr_ed_scalar_mul", p1, k)[0], oracle.call_pt("zr_ed_binary_naf_mul", p1, k)[0]) == 1
+
+
+def test_odd_multiples_table_affine(oracle, kats):
+    # constants.rs:216-972: entry 0 = identity, entry j>=1 = (2j-1)*B (affine equality only)
+    pts = kats["odd_multiples_table"]["points"]
+    assert len(pts) == 126
+    flat = np.array([sum(p, []) for p in pts], dtype=np.uint64)
+    b = tuple(pm.BASEPOINT)
+    twob = pm.ed_add(b, b)
+    want, cur = [pm.IDENT], b
+    for _ in range(125):
+        want.append(cur)
+        cur = pm.ed_add(cur, twob)
+    wflat = np.array([sum(pm.pt_limbs(w), []) for w in want], dtype=np.uint64)
+    assert oracle.ed_eq(flat, wflat).tolist() == [1] * 126
+
+
+# ------------------------------------------------------------------ ristretto.rs tests (:533-720)
+def test_ristretto_small_multiples(oracle, kats):
+    enc = [bytes.fromhex(x["hex"]) for x in kats["ristretto_small_multiples"]]
+    assert len(enc) == 16
+    bp = kats["constants_points"]["BASEPOINT"]["coords"]
+    b = [bp[c] for c in "XYZT"]
+    p = [ZERO, ONE, ONE, ZERO]
+    pmod = pm.IDENT
+    for i in range(16):
+        got = oracle.ris_compress(np.array([sum(p, [])], dtype=np.uint64))[0]
+        assert bytes(got.tolist()) == enc[i], i
+        assert pm.ris_compress(pmod) == enc[i], i
+        p = oracle.call_pt("zr_ed_add", p, b)[0]
+        pmod = pm.ed_add(pmod, pm.BASEPOINT)
+        assert pm.pt_limbs(pmod) == p  # limb-exact agreement of the two statements
+    assert kats["top_constants_bytes"]["RISTRETTO_BASEPOINT_COMPRESSED"]["bytes"] == list(enc[1])
+
+
+def test_ristretto_roundtrips(oracle, kats):
+    enc = [bytes.fromhex(x["hex"]) for x in kats["ristretto_small_multiples"]]
+    arr = np.frombuffer(b"".join(enc), dtype=np.uint8).reshape(16, 32)
+    pts, ok = oracle.ris_decompress(arr)
+    assert ok.tolist() == [1] * 16
+    assert oracle.ris_compress(pts).tolist() == arr.tolist()
+    # basepoint_compr_decompr: decompress(compress(B)) == B (Ristretto equality)
+    bp = kats["constants_points"]["BASEPOINT"]["coords"]
+    b = np.array([sum([bp[c] for c in "XYZT"], [])], dtype=np.uint64)
+    assert oracle.ris_eq(pts[1:2], b).tolist() == [1]
+    # four_torsion_diff: (B - decompress(compress(B))) * 4 compresses to the Edwards identity
+    diff = oracle.ed_sub(b, pts[1:2])
+    four = oracle.ed_mul_by_pow_2(diff, 2)
+    out, okc = oracle.ed_compress(four)
+    assert okc[0] == 1 and out[0].tolist() == [1] + [0] * 31
+    for i in range(16):
+        m = pm.ris_decompress(enc[i])
+        assert sum(pm.pt_limbs(m), []) == pts[i].tolist()
+
+
+def test_ristretto_order_8L_point(oracle, kats):
+    # validity_check (ristretto.rs:654-663): a valid Edwards point of order 8L
+    yb = kats["ristretto_inline_bytes"][0]["bytes"]
+    y = oracle.fe_from_bytes(np.array([yb], dtype=np.uint8))[0].tolist()
+    p, rc = oracle.call_pt("zr_ed_new_from_y_coord", y, 0)
+    lib = oracle.lib()
+    assert rc == 1 and lib.zr_ed_is_valid(C.byref(oracle._pt(p))) == 1
+    lp = oracle.call_pt("zr_ed_scalar_mul", p, cst(kats, "L"))[0]
+    ident = [ZERO, ONE, ONE, ZERO]
+    assert lib.zr_ed_eq(C.byref(oracle._pt(lp)), C.byref(oracle._pt(ident))) == 0
+
+
+def test_elligator_sage_vector(oracle, kats):
+    r0b = bytes.fromhex(kats["ristretto_elligator_hex"][0]["hex"])
+    exp = [x["limbs"] for x in kats["ristretto_elligator_point"]]
+    r0 = oracle.fe_from_bytes(np.frombuffer(r0b, dtype=np.uint8).reshape(1, 32))[0].tolist()
+    got, _ = oracle.call_pt("zr_ris_elligator", r0)
+    lib = oracle.lib()
+    assert lib.zr_ris_eq(C.byref(oracle._pt(got)), C.byref(oracle._pt(exp))) == 1
+    a = oracle.ris_compress(np.array([sum(got, [])], dtype=np.uint64))
+    b = oracle.ris_compress(np.array([sum(exp, [])], dtype=np.uint64))
+    assert a.tolist() == b.tolist()
+    assert pm.ris_eq(pm.elligator(pm.fe_from_bytes(r0b)), tuple(map(pm.from_limbs, exp)))
+
+
+# ------------------------------------------------------------------ bulk: oracle == independent model
+def _rand_fe(rng, n):
+    vals = [rng.randrange(pm.P) for _ in range(n)]
+    edge = [0, 1, 2, pm.P - 1, pm.P - 2, (pm.P - 1) // 2, (pm.P + 1) // 2, 2**52, 2**104, 2**156, 2**208, 2**252]
+    vals[:len(edge)] = edge
+    return vals
+
+
+def test_bulk_field_ops_vs_model(oracle):
+    rng = random.Random(0x5EED0001)
+    n = 3000
+    a, b = _rand_fe(rng, n), list(reversed(_rand_fe(rng, n)))
+    A = np.array([pm.limbs(x) for x in a], dtype=np.uint64)
+    B = np.array([pm.limbs(x) for x in b], dtype=np.uint64)
+    assert oracle.fe_mul(A, B).tolist() == [pm.limbs(x * y % pm.P) for x, y in zip(a, b)]
+    assert oracle.fe_add(A, B).tolist() == [pm.limbs((x + y) % pm.P) for x, y in zip(a, b)]
+    assert oracle.fe_sub(A, B).tolist() == [pm.limbs((x - y) % pm.P) for x, y in zip(a, b)]
+    assert oracle.fe_square(A).tolist() == [pm.limbs(x * x % pm.P) for x in a]
+    assert oracle.fe_neg(A).tolist() == [pm.limbs(-x % pm.P) for x in a]
+    inv, ok = oracle.fe_invert(A[:400])
+    assert ok.tolist() == [0 if x == 0 else 1 for x in a[:400]]
+    assert inv.tolist() == [pm.limbs(pow(x, -1, pm.P) if x else 0) for x in a[:400]]
+
+
+def test_bulk_scalar_ops_vs_model(oracle):
+    rng = random.Random(0x5EED0002)
+    n = 3000
+    a = [rng.randrange(pm.L) for _ in range(n)]
+    b = [rng.randrange(pm.L) for _ in range(n)]
+    a[:4] = [0, 1, pm.L - 1, pm.L - 2]
+    A = np.array([pm.limbs(x) for x in a], dtype=np.uint64)
+    B = np.array([pm.limbs(x) for x in b], dtype=np.uint64)
+    assert oracle.sc_mul(A, B).tolist() == [pm.limbs(x * y % pm.L) for x, y in zip(a, b)]
+    assert oracle.sc_add(A, B).tolist() == [pm.limbs((x + y) % pm.L) for x, y in zip(a, b)]
+    assert oracle.sc_sub(A, B).tolist() == [pm.limbs((x - y) % pm.L) for x, y in zip(a, b)]
+    assert oracle.sc_square(A).tolist() == [pm.limbs(x * x % pm.L) for x in a]
+
+
+def test_bulk_sqrt_ratio_vs_model(oracle):
+    rng = random.Random(0x5EED0003)
+    u = [rng.randrange(pm.P) for _ in range(60)]
+    v = [rng.randrange(pm.P) for _ in range(60)]
+    u[0], v[1] = 0, 0
+    out, sq = oracle.fe_sqrt_ratio_i(np.array([pm.limbs(x) for x in u], dtype=np.uint64),
+                                     np.array([pm.limbs(x) for x in v], dtype=np.uint64))
+    want = [pm.sqrt_ratio_i(x, y) for x, y in zip(u, v)]
+    assert sq.tolist() == [w[0] for w in want]
+    assert out.tolist() == [pm.limbs(w[1]) for w in want]
+    assert 0 < sum(sq.tolist()) < 60
+
+
+def test_bulk_scalar_mul_and_ristretto_vs_model(oracle):
+    rng = random.Random(0x5EED0004)
+    n = 24
+    pts, ks = [], []
+    for i in range(n):
+        r = rng.randrange(1, pm.L)
+        pts.append(pm.ed_scalar_mul(pm.BASEPOINT, r))
+        ks.append(rng.randrange(2**252) if i % 2 else rng.randrange(2**249))
+    ks[0], ks[1], ks[2] = 0, 1, pm.L
+    Pn = np.array([sum(pm.pt_limbs(p), []) for p in pts], dtype=np.uint64)
+    Kn = np.array([pm.limbs(k) for k in ks], dtype=np.uint64)
+    got = oracle.ed_scalar_mul(Pn, Kn)
+    want = [pm.ed_scalar_mul(p, k) for p, k in zip(pts, ks)]
+    assert got.tolist() == [sum(pm.pt_limbs(w), []) for w in want]        # strict (X:Y:Z:T) limbs
+    enc = oracle.ris_compress(got)
+    assert [bytes(e.tolist()) for e in enc] == [pm.ris_compress(w) for w in want]
+    cb, ok = oracle.ed_compress(got[3:])
+    assert ok.tolist() == [1] * (n - 3)
+    assert [bytes(e.tolist()) for e in cb] == [pm.ed_compress(w) for w in want[3:]]
+    dec, ok = oracle.ris_decompress(enc)
+    wdec = [pm.ris_decompress(bytes(e.tolist())) for e in enc]
+    assert ok.tolist() == [1 if w is not None else 0 for w in wdec]
+    for i, w in enumerate(wdec):
+        if w is not None:
+            assert dec[i].tolist() == sum(pm.pt_limbs(w), [])
+    # invalid / random encodings agree on acceptance
+    raw = [bytes([rng.randrange(256) for _ in range(31)] + [rng.randrange(16)]) for _ in range(40)]
+    d2, ok2 = oracle.ris_decompress(np.frombuffer(b"".join(raw), dtype=np.uint8).reshape(-1, 32))
+    w2 = [pm.ris_decompress(r) for r in raw]
+    assert ok2.tolist() == [1 if w is not None else 0 for w in w2]
+    assert 0 < sum(ok2.tolist()) < 40
