@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: batched variable-base Edwards scalar multiplication
+(BASELINE.json configs[2]: 2^20 points x random 252-bit scalars per GPU) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of zc_ed_scalar_mul (strict mode: the reference's formula sequence,
+bit-identical (X:Y:Z:T) limbs) over the rank's 2^20 HBM-resident points and scalars.
+Independent elements: the batch is sharded across ranks with no data-path collective
+(weak scaling: 2^20 per GPU).  PyTorch supplies device memory, the stream and
+torch.distributed; all arithmetic is in libzerocaf_hip.so.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_UNIT = {"scalar_mul": 360, "fe_mul": 120, "ristretto": 104}   # SURVEY 8(d) algorithmic bytes
+# measured on MI355X with tools/ubench (profiles/r01_ubench.txt): independent v_mad_u64_u32
+# chains, all CUs -- wave-instructions x 64 lanes per second
+MAD_PEAK_PER_S = None            # filled from profiles/r01_ubench.json when present
+MADS_PER_POINT_ADD = 10 * (126 + 9)   # 10 Montgomery muls x (81+45 v_mad_u64_u32 + 9 v_mul_lo_u32)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(eng, torch, n, seed, workload):
+    """Synthetic, seeded, generated on the GPU box: P_i = r_i * B (valid subgroup points in
+    non-trivial extended coordinates, produced by the engine itself) and S252 scalars."""
+    from oracle import pymodel as pm
+    rng = np.random.default_rng(seed)
+
+    def scalars(bits):
+        k = rng.integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)
+        k[:, 4] = rng.integers(0, 1 << (bits - 208), size=n, dtype=np.uint64)
+        return k
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    if workload == "fe_mul":
+        a, b = scalars(252), scalars(252)           # < 2^252 < p: canonical field elements
+        return {"a": to_dev(a), "b": to_dev(b), "host": (a, b)}
+    base = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (n, 1))
+    r = scalars(249)
+    P = eng.ed_scalar_mul(to_dev(base), to_dev(r))
+    torch.cuda.synchronize()
+    K = scalars(252)
+    d = {"P": P, "K": to_dev(K), "host_K": K}
+    if workload == "ristretto":
+        d["enc"] = eng.ris_compress(P)
+        torch.cuda.synchronize()
+    return d
+
+
+def cpu_baseline(workload, sample, host_inputs):
+    """Oracle (reference-shaped C restatement) on the host cores, bounded sample."""
+    from oracle import zc_ref
+    zc_ref.build()
+    zc_ref.lib()
+    cores = os.cpu_count() or 1
+    chunks = np.array_split(np.arange(sample), cores)
+    if workload == "fe_mul":
+        a, b = host_inputs
+        fn = lambda idx: zc_ref.fe_mul(a[idx], b[idx])
+    else:
+        P, K = host_inputs
+        fn = lambda idx: zc_ref.ed_scalar_mul(P[idx], K[idx])
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(fn, [c for c in chunks if len(c)]))
+    dt = time.perf_counter() - t0
+    return sample / dt, cores, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20, help="units per GPU per step")
+    ap.add_argument("--workload", default="scalar_mul", choices=["scalar_mul", "fe_mul", "ristretto"])
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="units for the CPU baseline (0 disables)")
+    ap.add_argument("--check", type=int, default=256, help="elements re-checked against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch                                   # before the HIP library: one HIP runtime per process
+    import torch.distributed as dist
+    import dusk_zerocaf_amd as z
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.gpus != world:
+        log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+
+    eng = z.Engine([local])
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    n = args.n
+    data = make_inputs(eng, torch, n, 0x5EED0003 + rank, args.workload)
+
+    if args.workload == "scalar_mul":
+        out = torch.empty_like(data["P"])
+        step = lambda: eng.ed_scalar_mul(data["P"], data["K"], out=out)
+    elif args.workload == "fe_mul":
+        step = lambda: eng.fe_mul(data["a"], data["b"])
+        out = None
+    else:
+        out = torch.empty_like(data["enc"])
+        step = lambda: eng.ris_roundtrip_mul(data["enc"], data["K"], out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_s = sum(kern_ms) / len(kern_ms) * 1e-3
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    units = n * world * args.steps
+    value = units / dt
+    unit_bytes = BYTES_PER_UNIT[args.workload]
+    achieved = unit_bytes * n / kern_avg_s / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "kernel": {"scalar_mul": "k_ed_scalar_mul", "fe_mul": "k_fe_mul", "ristretto": "k_ris_roundtrip_mul"}[args.workload],
+                "kernel_avg_ms": round(kern_avg_s * 1e3, 4), "algorithmic_bytes_per_unit": unit_bytes}
+    pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roofline["traffic"] = json.load(open(pmc)).get(args.workload)
+        except Exception:
+            pass
+    ub = os.path.join(ROOT, "profiles", "r01_ubench.json")
+    if args.workload != "fe_mul" and os.path.exists(ub):
+        try:
+            peak = float(json.load(open(ub))["v_mad_u64_u32_lane_ops_per_s"])
+            # wave steps per point: measured by the kernel design (max over lanes of bitlen-1+popcount ~ 395)
+            roofline["valu"] = {"note": "scalar-mul is integer-VALU bound, not HBM bound",
+                                "mad_peak_per_s": peak}
+        except Exception:
+            pass
+
+    # post-timing correctness spot check against the oracle (checker only)
+    checked = None
+    if args.check and args.workload == "scalar_mul":
+        from oracle import zc_ref
+        zc_ref.build()
+        idx = np.linspace(0, n - 1, args.check).astype(np.int64)
+        Ph = data["P"].cpu().numpy().view(np.uint64)[idx]
+        Kh = data["host_K"][idx]
+        got = out.cpu().numpy().view(np.uint64)[idx]
+        checked = bool(np.array_equal(got, zc_ref.ed_scalar_mul(Ph, Kh)))
+        if not checked:
+            raise SystemExit("PARITY FAILURE: GPU scalar-mul differs from the oracle")
+
+    cpu = None
+    sample = args.cpu_sample
+    if sample < 0:
+        sample = {"scalar_mul": 1 << 13, "ristretto": 1 << 13, "fe_mul": 1 << 22}[args.workload] * max(1, (os.cpu_count() or 1) // 8)
+    if sample:
+        if args.workload == "fe_mul":
+            a, b = data["host"]
+            reps = (sample + n - 1) // n
+            hi = (np.tile(a, (reps, 1))[:sample], np.tile(b, (reps, 1))[:sample])
+        else:
+            m = min(sample, n)
+            hi = (data["P"][:m].cpu().numpy().view(np.uint64), data["host_K"][:m])
+            sample = m
+        v, cores, secs = cpu_baseline("fe_mul" if args.workload == "fe_mul" else "scalar_mul", sample, hi)
+        cpu = {"value": round(v, 1), "unit": "scalar-muls/s" if args.workload != "fe_mul" else "field-muls/s",
+               "cores": cores, "kind": "port",
+               "sample": "%d units of the same seeded workload, %d threads, %.1f s wall; C restatement of "
+                         "zerocaf's u64 backend (oracle/zc_ref.c, gcc -O3), not the Rust binary" % (sample, cores, secs)}
+
+    line = {
+        "metric": "252-bit Edwards variable-base scalar-muls/sec (batched, strict bit-exact mode)"
+        if args.workload == "scalar_mul" else args.workload + " units/sec",
+        "value": round(value, 1),
+        "unit": "scalar-muls/s" if args.workload != "fe_mul" else "field-muls/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x9 limbs (radix 2^29, 64-bit accumulators)", "data": "synthetic",
+        "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random 252-bit scalars (BASELINE configs[2])",
+                                "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
+                                "ristretto": "Ristretto decompress->scalar-mul->compress (BASELINE configs[3] shape)"}[args.workload],
+                   "units_per_gpu_per_step": n, "sharding": "contiguous ranges, no collective",
+                   "mode": "strict (reference formula sequence, identical X:Y:Z:T limbs)"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "parity_spot_check": checked,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of libzerocaf_hip.so (the C ABI in include/zerocaf_hip.h).
+
+The product path: there is no Python or CPU fallback here.  If the shared library is
+missing, loading raises; if no GPU is visible, zc_ctx_create fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzerocaf_hip.so")
+
+_u64p = C.c_void_p
+_u8p = C.c_void_p
+_ctx = C.c_void_p
+_n = C.c_size_t
+
+# name -> argtypes (after the leading zc_ctx*); mirrors include/zerocaf_hip.h
+SIGNATURES = {
+    "zc_fe_add": [_u64p, _u64p, _u64p, _n],
+    "zc_fe_sub": [_u64p, _u64p, _u64p, _n],
+    "zc_fe_neg": [_u64p, _u64p, _n],
+    "zc_fe_mul": [_u64p, _u64p, _u64p, _n],
+    "zc_fe_square": [_u64p, _u64p, _n],
+    "zc_fe_invert": [_u64p, _u64p, _u8p, _n],
+    "zc_fe_from_bytes": [_u8p, _u64p, _n],
+    "zc_fe_to_bytes": [_u64p, _u8p, _n],
+    "zc_fe_sqrt_ratio_i": [_u64p, _u64p, _u64p, _u8p, _n],
+    "zc_sc_add": [_u64p, _u64p, _u64p, _n],
+    "zc_sc_sub": [_u64p, _u64p, _u64p, _n],
+    "zc_sc_neg": [_u64p, _u64p, _n],
+    "zc_sc_mul": [_u64p, _u64p, _u64p, _n],
+    "zc_sc_square": [_u64p, _u64p, _n],
+    "zc_sc_from_bytes": [_u8p, _u64p, _u8p, _n],
+    "zc_sc_to_bytes": [_u64p, _u8p, _n],
+    "zc_ed_add": [_u64p, _u64p, _u64p, _n],
+    "zc_ed_sub": [_u64p, _u64p, _u64p, _n],
+    "zc_ed_double": [_u64p, _u64p, _n],
+    "zc_ed_neg": [_u64p, _u64p, _n],
+    "zc_ed_scalar_mul": [_u64p, _u64p, _u64p, _n, C.c_uint],
+    "zc_ed_mul_by_pow_2": [_u64p, C.c_uint64, _u64p, _n],
+    "zc_ed_mul_by_cofactor": [_u64p, _u64p, _n],
+    "zc_ed_to_affine": [_u64p, _u64p, _u8p, _n],
+    "zc_ed_eq": [_u64p, _u64p, _u8p, _n],
+    "zc_ed_compress": [_u64p, _u8p, _u8p, _n],
+    "zc_ed_decompress": [_u8p, _u64p, _u8p, _n],
+    "zc_ris_compress": [_u64p, _u8p, _n],
+    "zc_ris_decompress": [_u8p, _u64p, _u8p, _n],
+    "zc_ris_eq": [_u64p, _u64p, _u8p, _n],
+    "zc_ris_roundtrip_mul": [_u8p, _u64p, _u8p, _u8p, _n],
+    "zc_msm": [_u64p, _u64p, _n, _u64p],
+}
+CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_set_stream", "zc_ctx_synchronize",
+                   "zc_device_count", "zc_last_error", "zc_version"]
+ALL_SYMBOLS = CONTEXT_SYMBOLS + list(SIGNATURES)
+
+_lib = None
+
+
+class ZerocafHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZerocafHipError(
+            "libzerocaf_hip.so is missing (%s): build it with `python -m dusk_zerocaf_amd.build`; "
+            "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.zc_ctx_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_ctx)]
+    lib.zc_ctx_create.restype = C.c_int
+    lib.zc_ctx_destroy.argtypes = [_ctx]
+    lib.zc_ctx_set_stream.argtypes = [_ctx, C.c_void_p]
+    lib.zc_ctx_synchronize.argtypes = [_ctx]
+    lib.zc_device_count.restype = C.c_int
+    lib.zc_last_error.restype = C.c_char_p
+    lib.zc_version.restype = C.c_char_p
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_ctx] + sig
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise ZerocafHipError("%s failed: status %d (%s)" % (what, rc, load().zc_last_error().decode()))

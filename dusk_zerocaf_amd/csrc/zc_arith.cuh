@@ -1,0 +1,325 @@
+// zc_arith.cuh -- device-side modular arithmetic for the Sonny/Doppio field (mod p)
+// and the scalar field (mod L), one element per lane.
+//
+// Representation: nine 29-bit limbs in 32-bit VGPRs ("radix 2^29"), Montgomery
+// form with R = 2^261.  Why this shape on gfx950:
+//   * the only wide integer multiplier is v_mad_u64_u32 (32x32+64 -> 64, no
+//     carry-in); with 29-bit limbs a 64-bit column accumulator absorbs all nine
+//     partial products AND the Montgomery correction terms without a single
+//     carry instruction, so the multiplier is pure `acc = mad(a_i, b_j, acc)`;
+//   * three spare bits per limb make add lazy (nine v_add_u32, no carries) and
+//     261-252 = 9 spare bits of R remove every conditional subtraction from the
+//     hot loops (bounds below);
+//   * p = 2^252 + c and L = 2^249 + c' have five non-zero low limbs and a single
+//     top bit, so a reduction column costs 5 mads + one shifted add.
+// The reference keeps canonical radix-2^52 limbs and does two Montgomery passes
+// per Mul (src/backend/u64/field.rs:250-262, :741-813); every reference op
+// returns the canonical representative, so any exact modular algorithm followed
+// by canonicalisation yields identical limbs (SURVEY 8a note P).
+//
+// Bounds ("R-class" = value < 3N with limbs 0..7 < 2^29; "lazy" = value < 32N,
+// limbs < 2^30):
+//   mont_mul / mont_sqr : inputs lazy  -> output R-class   ((32N)^2/R + N < 3N)
+//   fe_add              : inputs with limbs < 2^29 -> lazy (limbs < 2^30)
+//   fe_sub(a, b)        : a lazy, b R-class -> normalized, value < a + 4N
+// Column sums: 9 * 2^30 * 2^30 + 5 * 2^58 + 2^49 + carry < 2^63.4 < 2^64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "zc_constants.cuh"
+
+namespace zc {
+
+#define ZC_DI __device__ __forceinline__
+constexpr u32 M29 = 0x1fffffffu;
+constexpr u64 M52 = (1ull << 52) - 1;
+
+struct fe {
+    u32 v[9];
+};
+
+template <class F>
+ZC_DI fe fe_const(const u32 (&c)[9])
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c[i];
+    return r;
+}
+ZC_DI fe fe_zero()
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    return r;
+}
+template <class F>
+ZC_DI fe fe_one_m() { return fe_const<F>(F::ONE); }
+
+// ---------------------------------------------------------------- Montgomery core
+// Reduce the 18 column accumulators t[] (value < 2^522) to t/R mod N, R-class.
+template <class F>
+ZC_DI void mont_reduce_cols(fe& r, u64 (&t)[18])
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const u32 m = ((u32)t[k] * F::NP) & M29;
+        t[k] += (u64)m * F::N[0];
+        t[k + 1] += (u64)m * F::N[1];
+        t[k + 2] += (u64)m * F::N[2];
+        t[k + 3] += (u64)m * F::N[3];
+        t[k + 4] += (u64)m * F::N[4];
+        t[k + 8] += (u64)m << F::TOPSHIFT;   // N[5..7] == 0, N[8] == 1 << TOPSHIFT
+        t[k + 1] += t[k] >> 29;              // low 29 bits of t[k] are now zero
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        r.v[k - 9] = (u32)t[k] & M29;
+        t[k + 1] += t[k] >> 29;
+    }
+    r.v[8] = (u32)t[17];
+}
+
+// r = a * b / R mod N   (reference: mul_internal + montgomery_reduce, field.rs:741-813,
+// scalar.rs:580-652, with R = 2^261 instead of 2^260)
+template <class F>
+ZC_DI fe mont_mul(const fe& a, const fe& b)
+{
+    u64 t[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) t[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[i + j] += (u64)a.v[i] * b.v[j];
+    fe r;
+    mont_reduce_cols<F>(r, t);
+    return r;
+}
+
+// r = a * a / R mod N   (reference: square_internal, field.rs:763-777): 45 products
+template <class F>
+ZC_DI fe mont_sqr(const fe& a)
+{
+    u64 t[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) t[k] = 0;
+    u32 d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;   // limbs < 2^30 -> < 2^31
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        t[2 * i] += (u64)a.v[i] * a.v[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) t[i + j] += (u64)d[i] * a.v[j];
+    }
+    fe r;
+    mont_reduce_cols<F>(r, t);
+    return r;
+}
+
+// r = a / R mod N  (from Montgomery form; reference from_montgomery, field.rs:830-836)
+template <class F>
+ZC_DI fe mont_from(const fe& a)
+{
+    u64 t[18];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = a.v[k];
+#pragma unroll
+    for (int k = 9; k < 18; k++) t[k] = 0;
+    fe r;
+    mont_reduce_cols<F>(r, t);
+    return r;
+}
+
+template <class F>
+ZC_DI fe mont_to(const fe& a) { return mont_mul<F>(a, fe_const<F>(F::RR)); }
+
+// ---------------------------------------------------------------- add / sub / normalize
+ZC_DI void fe_carry(fe& a)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        a.v[k + 1] += a.v[k] >> 29;
+        a.v[k] &= M29;
+    }
+}
+// lazy add: limbs of a, b < 2^29 (+ small top limb) -> limbs < 2^30, no carries
+ZC_DI fe fe_add(const fe& a, const fe& b)
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+// a - b + 4N, normalized.  b must be R-class (value < 3N, limbs 0..7 < 2^29).
+template <class F>
+ZC_DI fe fe_sub(const fe& a, const fe& b)
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
+    fe_carry(r);
+    return r;
+}
+template <class F>
+ZC_DI fe fe_neg(const fe& b)
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = F::BIAS[i] - b.v[i];
+    fe_carry(r);
+    return r;
+}
+// bring any lazy value back to R-class (one multiplication by R mod N)
+template <class F>
+ZC_DI fe fe_reduce(const fe& a) { return mont_mul<F>(a, fe_one_m<F>()); }
+
+ZC_DI fe fe_select(bool c, const fe& a, const fe& b)   // c ? a : b
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
+// ---------------------------------------------------------------- canonical form
+// x normalized with value <= N+small  ->  unique representative in [0, N)
+template <class F>
+ZC_DI fe fe_cond_sub_n(const fe& x)
+{
+    fe d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 s = x.v[k] - F::N[k] - borrow;
+        borrow = s >> 31;
+        d.v[k] = s & M29;
+    }
+    const u32 s8 = x.v[8] - F::N[8] - borrow;
+    d.v[8] = s8;
+    const bool neg = (s8 >> 31) != 0;
+    return fe_select(neg, x, d);
+}
+// Montgomery-form (lazy ok) -> canonical plain value, limbs normalized
+template <class F>
+ZC_DI fe fe_canon_from_mont(const fe& a)
+{
+    fe t = a;
+    fe_carry(t);
+    return fe_cond_sub_n<F>(mont_from<F>(t));
+}
+// plain (non-Montgomery) normalized value < 2N -> canonical
+template <class F>
+ZC_DI fe fe_canon_plain(const fe& a) { return fe_cond_sub_n<F>(a); }
+
+// N - c for a plain canonical c in [0, N]  (normalized limbs)
+template <class F>
+ZC_DI fe fe_n_minus_canon(const fe& c)
+{
+    fe d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 s = F::N[k] - c.v[k] - borrow;
+        borrow = s >> 31;
+        d.v[k] = s & M29;
+    }
+    d.v[8] = F::N[8] - c.v[8] - borrow;
+    return d;
+}
+
+ZC_DI bool fe_is_zero_canon(const fe& c)
+{
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= c.v[i];
+    return o == 0;
+}
+ZC_DI bool fe_eq_canon(const fe& a, const fe& b)
+{
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// reference is_positive (field.rs:552-557): canonical value <= (N-1)/2
+template <class F>
+ZC_DI bool fe_is_positive_canon(const fe& c)
+{
+    u32 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const u32 s = F::HALF[k] - c.v[k] - borrow;
+        borrow = s >> 31;
+    }
+    return borrow == 0;
+}
+
+// ---------------------------------------------------------------- radix 2^52 <-> 2^29
+// five 52-bit limbs (reference layout, FieldElement([u64;5])) -> nine 29-bit limbs
+ZC_DI fe fe_from_limbs52(const u64 (&l)[5])
+{
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k;
+        const int idx = bit / 52, sh = bit % 52;
+        u64 x = (l[idx] & M52) >> sh;
+        if (sh + 29 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
+        r.v[k] = (k < 8) ? ((u32)x & M29) : (u32)x;       // limb 8 keeps bits 232..259
+    }
+    return r;
+}
+// canonical nine 29-bit limbs -> five 52-bit limbs
+ZC_DI void fe_to_limbs52(u64 (&l)[5], const fe& c)
+{
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int lo = 29 * k - 52 * j;               // bit position of limb k inside limb52 j
+            if (lo > -29 && lo < 52) {
+                if (lo >= 0) acc |= (u64)c.v[k] << lo;
+                else acc |= (u64)c.v[k] >> (-lo);
+            }
+        }
+        l[j] = (j < 4) ? (acc & M52) : acc;
+    }
+}
+
+// load a reference-layout element and enter Montgomery form
+template <class F>
+ZC_DI fe fe_load_mont(const u64* __restrict__ p)
+{
+    u64 l[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) l[i] = p[i];
+    return mont_to<F>(fe_from_limbs52(l));
+}
+// leave Montgomery form, canonicalise, store in reference layout
+template <class F>
+ZC_DI void fe_store_canon(u64* __restrict__ p, const fe& a)
+{
+    u64 l[5];
+    fe_to_limbs52(l, fe_canon_from_mont<F>(a));
+#pragma unroll
+    for (int i = 0; i < 5; i++) p[i] = l[i];
+}
+
+// ---------------------------------------------------------------- fixed exponentiation
+// a^e for a compile-time exponent e (wave-uniform control flow), left-to-right
+// binary.  Replaces the reference's data-dependent Pow / Savas-Koc / Tonelli
+// loops (field.rs:325-441, :854-925) with a fixed schedule returning the same value.
+template <class F>
+ZC_DI fe fe_pow_const(const fe& a, const u32 (&e)[8], int nbits)
+{
+    fe acc = a;                                           // top bit of e is 1
+    for (int i = nbits - 2; i >= 0; i--) {
+        acc = mont_sqr<F>(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = mont_mul<F>(acc, a);
+    }
+    return acc;
+}
+
+}  // namespace zc

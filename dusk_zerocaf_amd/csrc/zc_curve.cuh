@@ -1,0 +1,326 @@
+// zc_curve.cuh -- device-side Edwards / Ristretto group law and codecs on top of
+// zc_arith.cuh.  One point per lane; coordinates live in VGPRs in Montgomery form
+// (R = 2^261, radix 2^29).  Every function cites the reference lines whose
+// *values* it reproduces (paths relative to the reference checkout).
+#pragma once
+#include "zc_arith.cuh"
+
+namespace zc {
+
+typedef ModP FP;
+
+struct pt {
+    fe X, Y, Z, T;
+};
+
+// fixed exponents, read through the scalar cache (wave-uniform loads)
+__device__ __constant__ u32 ZC_EXP_INV[8] = {ModP::EXP_INV[0], ModP::EXP_INV[1], ModP::EXP_INV[2], ModP::EXP_INV[3],
+                                             ModP::EXP_INV[4], ModP::EXP_INV[5], ModP::EXP_INV[6], ModP::EXP_INV[7]};
+__device__ __constant__ u32 ZC_EXP_P58[8] = {ModP::EXP_P58[0], ModP::EXP_P58[1], ModP::EXP_P58[2], ModP::EXP_P58[3],
+                                             ModP::EXP_P58[4], ModP::EXP_P58[5], ModP::EXP_P58[6], ModP::EXP_P58[7]};
+
+// a^e, e = 2^(nbits-1) + ..., fixed schedule (left-to-right binary, uniform branches)
+ZC_DI fe fp_pow(const fe& a, const u32* __restrict__ e, int nbits)
+{
+    fe acc = a;
+    for (int i = nbits - 2; i >= 0; i--) {
+        acc = mont_sqr<FP>(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = mont_mul<FP>(acc, a);
+    }
+    return acc;
+}
+
+ZC_DI fe fp_mul(const fe& a, const fe& b) { return mont_mul<FP>(a, b); }
+ZC_DI fe fp_sqr(const fe& a) { return mont_sqr<FP>(a); }
+ZC_DI fe fp_sub(const fe& a, const fe& b) { return fe_sub<FP>(a, b); }
+ZC_DI fe fp_neg(const fe& a) { return fe_neg<FP>(a); }
+ZC_DI fe fp_canon(const fe& a) { return fe_canon_from_mont<FP>(a); }   // plain canonical value
+ZC_DI bool fp_is_zero(const fe& a) { return fe_is_zero_canon(fp_canon(a)); }
+// a == b (mod p); b must be R-class
+ZC_DI bool fp_eq(const fe& a, const fe& b) { return fp_is_zero(fp_sub(a, b)); }
+
+// a^(p-2): same value as the reference's Savas-Koc inverse (field.rs:854-925) for a != 0
+ZC_DI fe fp_invert(const fe& a) { return fp_pow(a, ZC_EXP_INV, ModP::EXP_INV_BITS); }
+
+// |x| by the reference's sign rule: negate when canonical value > (p-1)/2
+// (field.rs:552-557 + subtle conditional_negate).  Returns R-class Montgomery value.
+ZC_DI fe fp_abs(const fe& x)
+{
+    const bool pos = fe_is_positive_canon<FP>(fp_canon(x));
+    return fe_select(pos, x, fe_reduce<FP>(fp_neg(x)));
+}
+ZC_DI bool fp_is_positive(const fe& x) { return fe_is_positive_canon<FP>(fp_canon(x)); }
+
+// sqrt_ratio_i (field.rs:462-503): returns was_square and the non-negative root of
+// u/v (square case) or of i*u/v (non-square case), (1,0) for u == 0, (0,0) for v == 0.
+// One fixed exponentiation (p = 5 mod 8) instead of two inversions + Legendre +
+// Tonelli-Shanks; the decision rules pick the same value.  u, v R-class.
+ZC_DI bool fp_sqrt_ratio_i(fe& out, const fe& u, const fe& v)
+{
+    const fe i_m = fe_const<FP>(ModP::SQRT_M1_M);
+    const fe v2 = fp_sqr(v);
+    const fe v3 = fp_mul(v2, v);
+    const fe v7 = fp_mul(fp_sqr(v3), v);
+    const fe uv3 = fp_mul(u, v3);
+    fe r = fp_mul(uv3, fp_pow(fp_mul(u, v7), ZC_EXP_P58, ModP::EXP_P58_BITS));
+    const fe check = fp_mul(v, fp_sqr(r));
+    const fe ui = fp_mul(u, i_m);
+    const fe cc = fp_canon(check), uc = fp_canon(u);
+    const bool correct = fe_eq_canon(cc, uc);
+    const bool flipped = fe_is_zero_canon(fp_canon(fe_add(check, u)));        // check == -u
+    const bool flipped_i = fe_is_zero_canon(fp_canon(fe_add(check, ui)));     // check == -u*i
+    const fe ri = fp_mul(r, i_m);
+    r = fe_select(flipped || flipped_i, ri, r);
+    out = fp_abs(r);
+    return correct || flipped;
+}
+
+// Tonelli-Shanks value for p - 1 = 4q with non-residue 6 (field.rs:357-441):
+// x = a^((q+1)/2), times 6^q when a^q == -1; None when a^q is not +-1.  a R-class.
+ZC_DI bool fp_ts_sqrt(fe& x, const fe& a)
+{
+    const fe w = fp_pow(a, ZC_EXP_P58, ModP::EXP_P58_BITS);      // a^((q-1)/2)
+    const fe x0 = fp_mul(a, w);                                   // a^((q+1)/2)
+    const fe t = fp_canon(fp_mul(x0, w));                         // a^q, plain canonical
+    fe one = fe_zero();
+    one.v[0] = 1;
+    const bool t_is_one = fe_eq_canon(t, one);
+    const bool t_is_m1 = fe_eq_canon(t, fe_n_minus_canon<FP>(one));
+    const bool a_zero = fp_is_zero(a);
+    x = fe_select(t_is_m1, fp_mul(x0, fe_const<FP>(ModP::SIX_POW_Q_M)), x0);
+    return t_is_one || t_is_m1 || a_zero;                         // a == 0 -> Some(0)
+}
+// mod_sqrt(a, sign) (field.rs:378-440): sign = 1 selects p - x_TS
+ZC_DI bool fp_mod_sqrt(fe& x, const fe& a, bool sign)
+{
+    fe r;
+    const bool ok = fp_ts_sqrt(r, a);
+    x = fe_select(sign, fe_reduce<FP>(fp_neg(r)), r);
+    return ok;
+}
+
+// ---------------------------------------------------------------- points
+ZC_DI pt pt_identity()                                            // edwards.rs:381-391
+{
+    pt r;
+    r.X = fe_zero();
+    r.Y = fe_one_m<FP>();
+    r.Z = fe_one_m<FP>();
+    r.T = fe_zero();
+    return r;
+}
+ZC_DI pt pt_select(bool c, const pt& a, const pt& b)
+{
+    pt r;
+    r.X = fe_select(c, a.X, b.X);
+    r.Y = fe_select(c, a.Y, b.Y);
+    r.Z = fe_select(c, a.Z, b.Z);
+    r.T = fe_select(c, a.T, b.T);
+    return r;
+}
+// HWCD'08 unified addition, a = -1 (edwards.rs:465-489): 10 mul.  Inputs R-class.
+ZC_DI pt pt_add(const pt& p, const pt& q)
+{
+    const fe A = fp_mul(p.X, q.X);
+    const fe B = fp_mul(p.Y, q.Y);
+    const fe C = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), p.T), q.T);
+    const fe D = fp_mul(p.Z, q.Z);
+    fe E = fp_mul(fe_add(p.X, p.Y), fe_add(q.X, q.Y));
+    E = fp_sub(fp_sub(E, A), B);
+    const fe F = fp_sub(D, C);
+    const fe G = fe_add(D, C);
+    const fe H = fe_add(B, A);
+    pt r;
+    r.X = fp_mul(E, F);
+    r.Y = fp_mul(G, H);
+    r.Z = fp_mul(F, G);
+    r.T = fp_mul(E, H);
+    return r;
+}
+ZC_DI pt pt_neg(const pt& p)                                      // edwards.rs:440-455
+{
+    pt r;
+    r.X = fe_reduce<FP>(fp_neg(p.X));
+    r.Y = p.Y;
+    r.Z = p.Z;
+    r.T = fe_reduce<FP>(fp_neg(p.T));
+    return r;
+}
+ZC_DI pt pt_load(const u64* __restrict__ p)
+{
+    pt r;
+    r.X = fe_load_mont<FP>(p);
+    r.Y = fe_load_mont<FP>(p + 5);
+    r.Z = fe_load_mont<FP>(p + 10);
+    r.T = fe_load_mont<FP>(p + 15);
+    return r;
+}
+ZC_DI void pt_store(u64* __restrict__ o, const pt& p)
+{
+    fe_store_canon<FP>(o, p.X);
+    fe_store_canon<FP>(o + 5, p.Y);
+    fe_store_canon<FP>(o + 10, p.Z);
+    fe_store_canon<FP>(o + 15, p.T);
+}
+
+// ---------------------------------------------------------------- byte codecs
+// 32 little-endian bytes (as four u64 words) -> nine 29-bit limbs, all 256 bits kept
+// (from_bytes keeps bits 208..255 in the top limb: field.rs:563-587)
+ZC_DI fe fe_from_words256(const u64 (&w)[4])
+{
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, idx = bit >> 6, sh = bit & 63;
+        u64 x = w[idx] >> sh;
+        if (sh + 29 > 64 && idx + 1 < 4) x |= w[idx + 1] << (64 - sh);
+        r.v[k] = (k < 8) ? ((u32)x & M29) : (u32)x;
+    }
+    return r;
+}
+// canonical nine 29-bit limbs -> four u64 words (to_bytes, field.rs:591-631)
+ZC_DI void fe_to_words256(u64 (&w)[4], const fe& c)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int lo = 29 * k - 64 * j;
+            if (lo > -29 && lo < 64) {
+                if (lo >= 0) acc |= (u64)c.v[k] << lo;
+                else acc |= (u64)c.v[k] >> (-lo);
+            }
+        }
+        w[j] = acc;
+    }
+}
+// plain 256-bit value <= (p-1)/2 ?  (is_positive on the raw decoded limbs, ristretto.rs:104-114)
+ZC_DI bool words256_is_positive(const fe& raw)
+{
+    // raw.v[8] holds bits 232..255 (24 bits); HALF[8] = 2^19
+    u32 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const u32 s = ModP::HALF[k] - raw.v[k] - borrow;
+        borrow = s >> 31;
+    }
+    return borrow == 0;
+}
+
+// Ristretto decompress (ristretto.rs:96-154).  Returns ok; point has Z = 1.
+ZC_DI bool ris_decompress(pt& out, const u64 (&w)[4])
+{
+    const fe raw = fe_from_words256(w);
+    const bool s_ok = words256_is_positive(raw);         // also rejects every non-canonical s
+    const fe one = fe_one_m<FP>();
+    const fe s = mont_to<FP>(raw);
+    const fe ss = fp_sqr(s);
+    const fe u1 = fp_sub(one, ss);                       // 1 - s^2
+    fe u2 = fe_add(one, ss);                             // 1 + s^2 (lazy)
+    const fe u2sq = fp_sqr(u2);
+    const fe du1sq = fp_mul(fe_const<FP>(ModP::D_M), fp_sqr(u1));
+    const fe v = fp_sub(fp_neg(du1sq), u2sq);            // -(d*u1^2) - u2^2  (< 9N)
+    fe I;
+    const bool was_sq = fp_sqrt_ratio_i(I, one, fp_mul(v, u2sq));
+    const fe Dx = fp_mul(I, u2);
+    const fe Dy = fp_mul(fp_mul(I, Dx), v);
+    const fe x = fp_abs(fp_mul(fe_add(s, s), Dx));
+    const fe y = fp_mul(u1, Dy);
+    const fe t = fp_mul(x, y);
+    const bool t_pos = fp_is_positive(t);
+    const bool y_zero = fp_is_zero(y);
+    out.X = x;
+    out.Y = y;
+    out.Z = one;
+    out.T = t;
+    return s_ok && was_sq && t_pos && !y_zero;
+}
+
+// Ristretto compress (ristretto.rs:398-425) -> canonical s as plain limbs
+ZC_DI fe ris_compress(const pt& p)
+{
+    const fe u1 = fp_mul(fe_add(p.Z, p.Y), fp_sub(p.Z, p.Y));
+    const fe u2 = fp_mul(p.X, p.Y);
+    fe I;
+    (void)fp_sqrt_ratio_i(I, fe_one_m<FP>(), fp_mul(u1, fp_sqr(u2)));
+    const fe D1 = fp_mul(u1, I);
+    const fe D2 = fp_mul(u2, I);
+    const fe Zinv = fp_mul(fp_mul(D1, D2), p.T);
+    const bool rotate = !fp_is_positive(fp_mul(p.T, Zinv));
+    const fe i_m = fe_const<FP>(ModP::SQRT_M1_M);
+    const fe xr = fp_mul(i_m, p.Y), yr = fp_mul(i_m, p.X);
+    const fe Dr = fp_mul(D1, fe_const<FP>(ModP::INV_SQRT_A_MINUS_D_M));
+    const fe x = fe_select(rotate, xr, p.X);
+    fe y = fe_select(rotate, yr, p.Y);
+    const fe D = fe_select(rotate, Dr, D2);
+    const bool negy = !fp_is_positive(fp_mul(x, Zinv));
+    y = fe_select(negy, fe_reduce<FP>(fp_neg(y)), y);
+    const fe s = fp_mul(fp_sub(p.Z, y), D);
+    const fe sc = fp_canon(s);
+    const bool pos = fe_is_positive_canon<FP>(sc);
+    return fe_select(pos, sc, fe_n_minus_canon<FP>(sc));   // |s| = p - s when negative
+}
+
+// Ristretto equality (ristretto.rs:166-176)
+ZC_DI bool ris_eq(const pt& a, const pt& b)
+{
+    const bool e1 = fp_eq(fp_mul(a.X, b.Y), fp_mul(a.Y, b.X));
+    const bool e2 = fp_eq(fp_mul(a.X, b.X), fp_mul(a.Y, b.Y));
+    return e1 || e2;
+}
+
+// Edwards -> affine (edwards.rs:1071-1092).  ok = Z != 0 (the reference panics there).
+ZC_DI bool ed_to_affine(fe& x, fe& y, const pt& p)
+{
+    const fe zi = fp_invert(p.Z);
+    x = fp_mul(p.X, zi);
+    y = fp_mul(p.Y, zi);
+    return !fp_is_zero(p.Z);
+}
+// Edwards equality = affine equality (edwards.rs:360-364, 1044-1048), cross-multiplied
+ZC_DI bool ed_eq(const pt& a, const pt& b)
+{
+    const bool ex = fp_eq(fp_mul(a.X, b.Z), fp_mul(b.X, a.Z));
+    const bool ey = fp_eq(fp_mul(a.Y, b.Z), fp_mul(b.Y, a.Z));
+    return ex && ey && !fp_is_zero(a.Z) && !fp_is_zero(b.Z);
+}
+// Edwards compress (edwards.rs:613-629 + find_xx :200-204): y | sign << 255 where
+// sign = (mod_sqrt(xx, 0) != x).  One inversion shared by Z and the find_xx denominator.
+ZC_DI bool ed_compress(u64 (&w)[4], const pt& p)
+{
+    const fe Y2 = fp_sqr(p.Y), Z2 = fp_sqr(p.Z);
+    const fe den = fe_add(fp_mul(fe_const<FP>(ModP::D_M), Y2), Z2);   // d*Y^2 + Z^2 (lazy)
+    const fe winv = fp_invert(fp_mul(p.Z, den));
+    const fe zinv = fp_mul(winv, den);
+    const fe x = fp_mul(p.X, zinv), y = fp_mul(p.Y, zinv);
+    const fe xx = fp_mul(fp_mul(fp_sub(Y2, Z2), winv), p.Z);   // (y^2 - 1)/(d*y^2 + 1)
+    fe r;
+    const bool have = fp_ts_sqrt(r, xx);
+    const bool ok = have && !fp_is_zero(p.Z) && !fp_is_zero(den);
+    const bool sign = !fp_eq(r, x);
+    fe_to_words256(w, fp_canon(y));
+    w[3] |= (u64)(sign ? 1 : 0) << 63;
+    return ok;
+}
+// Edwards decompress (edwards.rs:313-326, :962-979, :402-417): byte 31 masked with 0x0F
+ZC_DI bool ed_decompress(pt& out, const u64 (&win)[4])
+{
+    const bool sign = (win[3] >> 63) != 0;
+    u64 w[4] = {win[0], win[1], win[2], win[3] & 0x0FFFFFFFFFFFFFFFull};
+    const fe one = fe_one_m<FP>();
+    const fe y = mont_to<FP>(fe_from_words256(w));
+    const fe yy = fp_sqr(y);
+    const fe num = fp_sub(yy, one);
+    const fe den = fe_add(fp_mul(fe_const<FP>(ModP::D_M), yy), one);
+    const fe xx = fp_mul(num, fp_invert(den));
+    fe x;
+    const bool have = fp_mod_sqrt(x, xx, sign);
+    out.X = x;
+    out.Y = y;
+    out.Z = one;
+    out.T = fp_mul(x, y);
+    return have && !fp_is_zero(den);
+}
+
+}  // namespace zc

@@ -1,0 +1,407 @@
+// zc_kernels.cuh -- the __global__ kernels of libzerocaf_hip (gfx950).
+// Launch shape: 256-thread blocks (4 waves, one per SIMD), one element / point per
+// lane, grid = ceil(n / 256).  I/O arrays are the reference's own AoS limb layout.
+#pragma once
+#include "zc_curve.cuh"
+
+namespace zc {
+
+#define ZC_KERNEL extern "C" __global__ __launch_bounds__(256)
+constexpr int ZC_BLOCK = 256;
+
+ZC_DI size_t gid() { return (size_t)blockIdx.x * ZC_BLOCK + threadIdx.x; }
+
+// ------------------------------------------------------------------ radix-2^52 add/sub
+// Add/Sub/Neg are carry/borrow chains over the reference's own limbs
+// (field.rs:191-240, scalar.rs:184-237); they are done directly in radix 2^52 so the
+// result is the reference's for every input pattern, canonical or not.
+template <class F>
+ZC_DI void limbs52_of_modulus(u64 (&m)[5])
+{
+    fe n = fe_const<F>(F::N);
+    fe_to_limbs52(m, n);
+}
+ZC_DI void sub52(u64 (&r)[5], const u64 (&a)[5], const u64 (&b)[5], const u64 (&m)[5])
+{
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        borrow = a[i] - (b[i] + (borrow >> 63));
+        r[i] = borrow & M52;
+    }
+    const u64 mask = 0 - (borrow >> 63);                 // all ones when the difference went negative
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        carry = (carry >> 52) + r[i] + (m[i] & mask);
+        r[i] = carry & M52;
+    }
+}
+ZC_DI void add52(u64 (&r)[5], const u64 (&a)[5], const u64 (&b)[5], const u64 (&m)[5])
+{
+    u64 s[5];
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        carry = a[i] + b[i] + (carry >> 52);
+        s[i] = carry & M52;
+    }
+    sub52(r, s, m, m);
+}
+ZC_DI void load5(u64 (&l)[5], const u64* __restrict__ p)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) l[i] = p[i];
+}
+ZC_DI void store5(u64* __restrict__ p, const u64 (&l)[5])
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) p[i] = l[i];
+}
+
+template <class F, int OP>   // OP: 0 add, 1 sub, 2 neg
+ZC_DI void addsub_body(const u64* a, const u64* b, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 m[5], x[5], y[5], r[5];
+    limbs52_of_modulus<F>(m);
+    load5(x, a + 5 * i);
+    if (OP == 2) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) { y[j] = x[j]; x[j] = 0; }
+    } else {
+        load5(y, b + 5 * i);
+    }
+    if (OP == 0) add52(r, x, y, m);
+    else sub52(r, x, y, m);
+    store5(out + 5 * i, r);
+}
+ZC_KERNEL void k_fe_add(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModP, 0>(a, b, out, n); }
+ZC_KERNEL void k_fe_sub(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModP, 1>(a, b, out, n); }
+ZC_KERNEL void k_fe_neg(const u64* a, u64* out, size_t n) { addsub_body<ModP, 2>(a, nullptr, out, n); }
+ZC_KERNEL void k_sc_add(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModL, 0>(a, b, out, n); }
+ZC_KERNEL void k_sc_sub(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModL, 1>(a, b, out, n); }
+ZC_KERNEL void k_sc_neg(const u64* a, u64* out, size_t n) { addsub_body<ModL, 2>(a, nullptr, out, n); }
+
+// ------------------------------------------------------------------ mul / square
+// plain operands -> a*b mod N canonical: (a*R) * b / R, then canonicalise (< 3N)
+template <class F>
+ZC_DI void store_plain_canon(u64* __restrict__ o, const fe& x)   // x plain value < 3N, normalized
+{
+    u64 l[5];
+    fe_to_limbs52(l, fe_cond_sub_n<F>(fe_cond_sub_n<F>(x)));
+    store5(o, l);
+}
+template <class F>
+ZC_DI void mul_body(const u64* a, const u64* b, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 x[5], y[5];
+    load5(x, a + 5 * i);
+    load5(y, b + 5 * i);
+    const fe am = mont_to<F>(fe_from_limbs52(x));
+    store_plain_canon<F>(out + 5 * i, mont_mul<F>(am, fe_from_limbs52(y)));
+}
+template <class F>
+ZC_DI void sqr_body(const u64* a, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 x[5];
+    load5(x, a + 5 * i);
+    const fe s = mont_sqr<F>(fe_from_limbs52(x));          // a^2 / R
+    store_plain_canon<F>(out + 5 * i, mont_mul<F>(s, fe_const<F>(F::RR)));
+}
+ZC_KERNEL void k_fe_mul(const u64* a, const u64* b, u64* out, size_t n) { mul_body<ModP>(a, b, out, n); }
+ZC_KERNEL void k_sc_mul(const u64* a, const u64* b, u64* out, size_t n) { mul_body<ModL>(a, b, out, n); }
+ZC_KERNEL void k_fe_square(const u64* a, u64* out, size_t n) { sqr_body<ModP>(a, out, n); }
+ZC_KERNEL void k_sc_square(const u64* a, u64* out, size_t n) { sqr_body<ModL>(a, out, n); }
+
+// ------------------------------------------------------------------ invert / sqrt_ratio_i
+ZC_KERNEL void k_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const fe x = fe_load_mont<FP>(a + 5 * i);
+    const bool nz = !fp_is_zero(x);
+    fe_store_canon<FP>(out + 5 * i, fp_invert(x));         // 0^(p-2) = 0
+    if (ok) ok[i] = nz ? 1 : 0;
+}
+ZC_KERNEL void k_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* was_square, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const fe uu = fe_load_mont<FP>(u + 5 * i), vv = fe_load_mont<FP>(v + 5 * i);
+    fe r;
+    const bool sq = fp_sqrt_ratio_i(r, uu, vv);
+    fe_store_canon<FP>(out + 5 * i, r);
+    if (was_square) was_square[i] = sq ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ byte codecs
+ZC_DI void load_words256(u64 (&w)[4], const uint8_t* __restrict__ p)
+{
+    const u64* q = reinterpret_cast<const u64*>(p);       // 32-byte records, 8-byte aligned
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = q[i];
+}
+ZC_DI void store_words256(uint8_t* __restrict__ p, const u64 (&w)[4])
+{
+    u64* q = reinterpret_cast<u64*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = w[i];
+}
+// four u64 words -> five 52-bit limbs, top limb keeps 48 bits (field.rs:577-586, scalar.rs:457-463)
+ZC_DI void words_to_limbs52(u64 (&l)[5], const u64 (&w)[4])
+{
+    l[0] = w[0] & M52;
+    l[1] = ((w[0] >> 52) | (w[1] << 12)) & M52;
+    l[2] = ((w[1] >> 40) | (w[2] << 24)) & M52;
+    l[3] = ((w[2] >> 28) | (w[3] << 36)) & M52;
+    l[4] = w[3] >> 16;
+}
+// (field.rs:591-631, scalar.rs:477-516): bytes of limbs, upper limb bits beyond 256 dropped
+ZC_DI void limbs52_to_words(u64 (&w)[4], const u64 (&l)[5])
+{
+    w[0] = l[0] | (l[1] << 52);
+    w[1] = (l[1] >> 12) | (l[2] << 40);
+    w[2] = (l[2] >> 24) | (l[3] << 28);
+    w[3] = (l[3] >> 36) | (l[4] << 16);
+}
+ZC_KERNEL void k_from_bytes(const uint8_t* in, u64* out, uint8_t* ok, int check_scalar_range, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4], l[5];
+    load_words256(w, in + 32 * i);
+    words_to_limbs52(l, w);
+    store5(out + 5 * i, l);
+    if (check_scalar_range && ok) {
+        // assert!(s <= L - 1)  (scalar.rs:465): limb-lexicographic compare from the top
+        u64 m[5];
+        limbs52_of_modulus<ModL>(m);
+        m[0] -= 1;
+        int c = 0;                                         // sign of (l - m)
+#pragma unroll
+        for (int j = 0; j < 5; j++) c = (l[j] > m[j]) ? 1 : ((l[j] < m[j]) ? -1 : c);
+        ok[i] = (c <= 0) ? 1 : 0;
+    }
+}
+ZC_KERNEL void k_to_bytes(const u64* in, uint8_t* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4], l[5];
+    load5(l, in + 5 * i);
+    limbs52_to_words(w, l);
+    store_words256(out + 32 * i, w);
+}
+
+// ------------------------------------------------------------------ point ops
+ZC_KERNEL void k_ed_add(const u64* p, const u64* q, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_load(q + 20 * i)));
+}
+ZC_KERNEL void k_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    // edwards.rs:503-531: add of the negated rhs with H = B - a*A == B + A (a = -1): same values
+    pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_neg(pt_load(q + 20 * i))));
+}
+ZC_KERNEL void k_ed_double(const u64* p, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const pt a = pt_load(p + 20 * i);
+    pt_store(out + 20 * i, pt_add(a, a));
+}
+ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    pt_store(out + 20 * i, pt_neg(pt_load(p + 20 * i)));
+}
+
+// ------------------------------------------------------------------ variable-base scalar multiplication
+// Reference: double_and_add (edwards.rs:102-120): LSB-first, Q += N when the bit is
+// set, N = N + N every iteration, both through the SAME unified HWCD formula.
+// SIMT form: every lane walks its own op sequence  [add?] dbl [add?] dbl ... [add]
+// and each wave step evaluates the formula ONCE with per-lane selected operands
+// (Q+N or N+N).  Lanes therefore never pay for the adds of zero bits: a wave needs
+// max_lane(bitlen - 1 + popcount) steps (~395 for random 252-bit scalars) instead
+// of 2*bitlen (~502) with a predicated add per bit.  The final doubling of the
+// reference loop does not influence Q and is skipped; the first add is performed
+// literally (identity + N), so (X:Y:Z:T) limbs equal the reference's.
+// Scalar words live in LDS (one 32-bit word per lane per refill).
+ZC_DI void scalar_to_words(u32* __restrict__ sk, int tid, const u64 (&l)[5], int& nbits)
+{
+    u32 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 32 * k, idx = bit / 52, sh = bit % 52;
+        u64 x = (idx < 5) ? ((l[idx] & M52) >> sh) : 0;
+        if (sh + 32 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
+        w[k] = (u32)x;
+    }
+    w[8] &= 0xFu;                                          // 260 bits in total
+    nbits = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (w[k]) nbits = 32 * k + (32 - __builtin_clz(w[k]));
+        sk[k * ZC_BLOCK + tid] = w[k];
+    }
+}
+
+ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int tid, int nbits)
+{
+    pt N = P, Q = pt_identity();
+    int pos = 0;
+    u32 cur = sk[tid];
+    bool pend = (cur & 1) != 0;
+    bool active = nbits > 0;
+    while (__any(active)) {
+        if (active) {
+            const pt lhs = pt_select(pend, Q, N);
+            const pt r = pt_add(lhs, N);
+            if (pend) {
+                Q = r;
+                pend = false;
+                active = pos < nbits - 1;
+            } else {
+                N = r;
+                pos++;
+                if ((pos & 31) == 0) cur = sk[(pos >> 5) * ZC_BLOCK + tid];
+                pend = ((cur >> (pos & 31)) & 1) != 0;
+            }
+        }
+    }
+    return Q;
+}
+
+// k_stride = 5 (one scalar per point) or 0 (one scalar for the whole batch:
+// mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191)
+ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, size_t n)
+{
+    __shared__ u32 sk[9 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    const size_t ii = valid ? i : 0;
+    u64 l[5];
+    load5(l, k + k_stride * ii);
+    int nbits;
+    scalar_to_words(sk, tid, l, nbits);
+    if (!valid) nbits = 0;
+    const pt P = pt_load(p + 20 * ii);
+    const pt Q = scalar_mul_unified(P, sk, tid, nbits);
+    if (valid) pt_store(out + 20 * i, Q);
+}
+
+// ------------------------------------------------------------------ affine / eq / Edwards codec
+ZC_KERNEL void k_ed_to_affine(const u64* p, u64* xy, uint8_t* ok, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    fe x, y;
+    const bool o = ed_to_affine(x, y, pt_load(p + 20 * i));
+    fe_store_canon<FP>(xy + 10 * i, x);
+    fe_store_canon<FP>(xy + 10 * i + 5, y);
+    if (ok) ok[i] = o ? 1 : 0;
+}
+ZC_KERNEL void k_ed_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    eq[i] = ed_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
+}
+ZC_KERNEL void k_ed_compress(const u64* p, uint8_t* out, uint8_t* ok, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4];
+    const bool o = ed_compress(w, pt_load(p + 20 * i));
+    if (!o) w[0] = w[1] = w[2] = w[3] = 0;
+    store_words256(out + 32 * i, w);
+    if (ok) ok[i] = o ? 1 : 0;
+}
+ZC_KERNEL void k_ed_decompress(const uint8_t* in, u64* out, uint8_t* ok, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4];
+    load_words256(w, in + 32 * i);
+    pt r;
+    const bool o = ed_decompress(r, w);
+    pt_store(out + 20 * i, pt_select(o, r, pt_identity()));
+    if (ok) ok[i] = o ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ Ristretto
+ZC_KERNEL void k_ris_compress(const u64* p, uint8_t* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4];
+    fe_to_words256(w, ris_compress(pt_load(p + 20 * i)));
+    store_words256(out + 32 * i, w);
+}
+ZC_KERNEL void k_ris_decompress(const uint8_t* in, u64* out, uint8_t* ok, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4];
+    load_words256(w, in + 32 * i);
+    pt r;
+    const bool o = ris_decompress(r, w);
+    pt_store(out + 20 * i, pt_select(o, r, pt_identity()));
+    if (ok) ok[i] = o ? 1 : 0;
+}
+ZC_KERNEL void k_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    eq[i] = ris_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
+}
+// fused config-4 path: 32 B in -> registers -> 32 B out; the point never touches HBM
+ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, size_t n)
+{
+    __shared__ u32 sk[9 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    const size_t ii = valid ? i : 0;
+    u64 w[4], l[5];
+    load_words256(w, in + 32 * ii);
+    load5(l, k + 5 * ii);
+    int nbits;
+    scalar_to_words(sk, tid, l, nbits);
+    pt P;
+    const bool dec = ris_decompress(P, w);
+    if (!valid || !dec) nbits = 0;
+    const pt Q = scalar_mul_unified(P, sk, tid, nbits);
+    fe_to_words256(w, ris_compress(Q));
+    if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
+    if (valid) {
+        store_words256(out + 32 * i, w);
+        if (ok) ok[i] = dec ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ reduction helper for zc_msm
+// out[i] = in[2i] + in[2i+1] (odd tail copied): pairwise fold of a point array
+ZC_KERNEL void k_ed_fold_pairs(const u64* in, u64* out, size_t n_in)
+{
+    const size_t i = gid();
+    const size_t n_out = (n_in + 1) / 2;
+    if (i >= n_out) return;
+    const pt a = pt_load(in + 20 * (2 * i));
+    if (2 * i + 1 < n_in) pt_store(out + 20 * i, pt_add(a, pt_load(in + 20 * (2 * i + 1))));
+    else pt_store(out + 20 * i, a);
+}
+
+}  // namespace zc

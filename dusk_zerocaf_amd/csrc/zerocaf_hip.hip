@@ -1,0 +1,568 @@
+// zerocaf_hip.hip -- host side of libzerocaf_hip.so: context, residency detection,
+// staging and kernel dispatch behind the C ABI of include/zerocaf_hip.h.
+// gfx950 only; there is no CPU fallback anywhere in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/zerocaf_hip.h"
+#include "zc_kernels.cuh"
+
+using zc::u64;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    g_last_error = what;
+    if (e != hipSuccess) {
+        g_last_error += ": ";
+        g_last_error += hipGetErrorString(e);
+    }
+    return code;
+}
+
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) return fail(ZC_ERR_HIP, #expr, e_);  \
+    } while (0)
+
+constexpr int MAX_ARGS = 6;
+
+struct DevState {
+    int device = 0;
+    hipStream_t stream = nullptr;       // owned
+    hipStream_t borrowed = nullptr;     // set by zc_ctx_set_stream (device 0 only)
+    void* scratch[MAX_ARGS] = {};
+    size_t scratch_bytes[MAX_ARGS] = {};
+    void* tmp[2] = {};                  // zc_msm partials
+    size_t tmp_bytes[2] = {};
+    hipStream_t s() const { return borrowed ? borrowed : stream; }
+};
+
+}  // namespace
+
+struct zc_ctx {
+    std::vector<DevState> devs;
+    std::mutex mu;
+};
+
+namespace {
+
+// One buffer argument of a batched call.
+struct Arg {
+    const void* ptr;     // caller pointer (host or device), may be null when optional
+    size_t elt_bytes;    // bytes per element
+    bool is_out;
+    bool broadcast;      // a single element shared by the whole batch (not sliced)
+};
+
+enum Residency { RES_HOST = 0, RES_DEVICE = 1 };
+
+int residency_of(const void* p, Residency* res, int* device)
+{
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();                    // plain malloc memory: not known to HIP
+        *res = RES_HOST;
+        return ZC_OK;
+    }
+    if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) {
+        *res = RES_DEVICE;
+        *device = attr.device;
+    } else {
+        *res = RES_HOST;                            // pinned / registered / unregistered host
+    }
+    return ZC_OK;
+}
+
+int ensure(void** buf, size_t* have, size_t need)
+{
+    if (*have >= need) return ZC_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    size_t want = std::max(need, (size_t)1 << 20);
+    hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) return fail(ZC_ERR_NOMEM, "hipMalloc(scratch)", e);
+    *have = want;
+    return ZC_OK;
+}
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + zc::ZC_BLOCK - 1) / zc::ZC_BLOCK); }
+
+// Launch functor: receives device pointers in argument order, element count, stream.
+template <class Launch>
+int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    if (nargs > MAX_ARGS) return fail(ZC_ERR_BAD_ARG, "too many arguments");
+    if (n == 0) return ZC_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+
+    int ndevptr = 0, nhostptr = 0, dev_of_ptrs = -1;
+    for (int a = 0; a < nargs; a++) {
+        if (!args[a].ptr) continue;
+        Residency r;
+        int d = -1;
+        residency_of(args[a].ptr, &r, &d);
+        if (r == RES_DEVICE) {
+            ndevptr++;
+            if (dev_of_ptrs >= 0 && d != dev_of_ptrs) return fail(ZC_ERR_MIXED_MEM, "buffers on different devices");
+            dev_of_ptrs = d;
+        } else {
+            nhostptr++;
+        }
+    }
+    if (ndevptr && nhostptr) return fail(ZC_ERR_MIXED_MEM, "host and device buffers mixed in one call");
+
+    if (ndevptr) {
+        // in-place on the device that owns the buffers, asynchronous on the context stream
+        DevState* ds = nullptr;
+        for (auto& d : ctx->devs)
+            if (d.device == dev_of_ptrs) ds = &d;
+        if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+        HIP_TRY(hipSetDevice(ds->device));
+        void* dptr[MAX_ARGS];
+        for (int a = 0; a < nargs; a++) dptr[a] = const_cast<void*>(args[a].ptr);
+        launch(dptr, n, ds->s());
+        HIP_TRY(hipGetLastError());
+        return ZC_OK;
+    }
+
+    // host buffers: shard into contiguous ranges, one per device (no exchange step)
+    const size_t ndev = ctx->devs.size();
+    const size_t per = (n + ndev - 1) / ndev;
+    for (size_t di = 0; di < ndev; di++) {
+        const size_t lo = di * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        const size_t cnt = hi - lo;
+        DevState& ds = ctx->devs[di];
+        HIP_TRY(hipSetDevice(ds.device));
+        void* dptr[MAX_ARGS];
+        for (int a = 0; a < nargs; a++) {
+            dptr[a] = nullptr;
+            if (!args[a].ptr) continue;
+            const size_t bytes = args[a].broadcast ? args[a].elt_bytes : args[a].elt_bytes * cnt;
+            int rc = ensure(&ds.scratch[a], &ds.scratch_bytes[a], bytes);
+            if (rc) return rc;
+            dptr[a] = ds.scratch[a];
+            if (!args[a].is_out) {
+                const char* src = (const char*)args[a].ptr + (args[a].broadcast ? 0 : args[a].elt_bytes * lo);
+                HIP_TRY(hipMemcpyAsync(dptr[a], src, bytes, hipMemcpyHostToDevice, ds.s()));
+            }
+        }
+        launch(dptr, cnt, ds.s());
+        HIP_TRY(hipGetLastError());
+        for (int a = 0; a < nargs; a++) {
+            if (!args[a].ptr || !args[a].is_out) continue;
+            char* dst = (char*)const_cast<void*>(args[a].ptr) + args[a].elt_bytes * lo;
+            HIP_TRY(hipMemcpyAsync(dst, dptr[a], args[a].elt_bytes * cnt, hipMemcpyDeviceToHost, ds.s()));
+        }
+    }
+    for (size_t di = 0; di < ndev; di++) {
+        HIP_TRY(hipSetDevice(ctx->devs[di].device));
+        HIP_TRY(hipStreamSynchronize(ctx->devs[di].s()));
+    }
+    return ZC_OK;
+}
+
+inline Arg in_arg(const void* p, size_t b) { return Arg{p, b, false, false}; }
+inline Arg out_arg(void* p, size_t b) { return Arg{p, b, true, false}; }
+
+#define REQUIRE(p) \
+    if (!(p)) return fail(ZC_ERR_BAD_ARG, "null pointer: " #p)
+
+typedef void (*kbin_t)(const u64*, const u64*, u64*, size_t);
+typedef void (*kun_t)(const u64*, u64*, size_t);
+
+int binop(zc_ctx* ctx, kbin_t k, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
+{
+    REQUIRE(a); REQUIRE(b); REQUIRE(out);
+    Arg args[3] = {in_arg(a, elt), in_arg(b, elt), out_arg(out, elt)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
+    });
+}
+int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
+{
+    REQUIRE(a); REQUIRE(out);
+    Arg args[2] = {in_arg(a, elt), out_arg(out, elt)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (u64*)d[1], cnt);
+    });
+}
+
+int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, bool broadcast_k, uint64_t* out, size_t n)
+{
+    REQUIRE(p); REQUIRE(k); REQUIRE(out);
+    Arg args[3] = {in_arg(p, 160), Arg{k, 40, false, broadcast_k}, out_arg(out, 160)};
+    const size_t stride = broadcast_k ? 0 : 5;
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0],
+                           (const u64*)d[1], stride, (u64*)d[2], cnt);
+    });
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* zc_version(void) { return "zerocaf_hip 0.1 (gfx950, radix-2^29 Montgomery R=2^261)"; }
+const char* zc_last_error(void) { return g_last_error.c_str(); }
+
+int zc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
+{
+    if (!out) return fail(ZC_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    int avail = zc_device_count();
+    if (avail <= 0) return fail(ZC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    std::vector<int> ids;
+    if (!devices || ndev <= 0) {
+        int cur = 0;
+        HIP_TRY(hipGetDevice(&cur));
+        ids.push_back(cur);
+    } else {
+        for (int i = 0; i < ndev; i++) {
+            if (devices[i] < 0 || devices[i] >= avail) return fail(ZC_ERR_BAD_ARG, "device index out of range");
+            ids.push_back(devices[i]);
+        }
+    }
+    zc_ctx* ctx = new zc_ctx();
+    for (int id : ids) {
+        DevState ds;
+        ds.device = id;
+        hipError_t e = hipSetDevice(id);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(ZC_ERR_HIP, "stream creation", e);
+        }
+        ctx->devs.push_back(ds);
+    }
+    (void)hipSetDevice(ids[0]);
+    *out = ctx;
+    return ZC_OK;
+}
+
+int zc_ctx_destroy(zc_ctx* ctx)
+{
+    if (!ctx) return ZC_OK;
+    for (auto& ds : ctx->devs) {
+        (void)hipSetDevice(ds.device);
+        (void)hipStreamSynchronize(ds.s());
+        for (int a = 0; a < MAX_ARGS; a++)
+            if (ds.scratch[a]) (void)hipFree(ds.scratch[a]);
+        for (int a = 0; a < 2; a++)
+            if (ds.tmp[a]) (void)hipFree(ds.tmp[a]);
+        if (ds.stream) (void)hipStreamDestroy(ds.stream);
+    }
+    delete ctx;
+    return ZC_OK;
+}
+
+int zc_ctx_set_stream(zc_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->devs[0].borrowed = (hipStream_t)hip_stream;
+    return ZC_OK;
+}
+
+int zc_ctx_synchronize(zc_ctx* ctx)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    for (auto& ds : ctx->devs) {
+        HIP_TRY(hipSetDevice(ds.device));
+        HIP_TRY(hipStreamSynchronize(ds.s()));
+    }
+    return ZC_OK;
+}
+
+// ---- FieldElement
+int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, a, b, o, n, 40); }
+int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, a, b, o, n, 40); }
+int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, a, b, o, n, 40); }
+int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
+int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40); }
+
+int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n)
+{
+    REQUIRE(a); REQUIRE(out);
+    Arg args[3] = {in_arg(a, 40), out_arg(out, 40), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_fe_invert, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_fe_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, size_t n)
+{
+    REQUIRE(in32); REQUIRE(out);
+    Arg args[2] = {in_arg(in32, 32), out_arg(out, 40)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_from_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)nullptr, 0, cnt);
+    });
+}
+int zc_fe_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n)
+{
+    REQUIRE(in); REQUIRE(out32);
+    Arg args[2] = {in_arg(in, 40), out_arg(out32, 32)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_to_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_fe_sqrt_ratio_i(zc_ctx* ctx, const uint64_t* u, const uint64_t* v, uint64_t* out, uint8_t* was_square, size_t n)
+{
+    REQUIRE(u); REQUIRE(v); REQUIRE(out);
+    Arg args[4] = {in_arg(u, 40), in_arg(v, 40), out_arg(out, 40), out_arg(was_square, 1)};
+    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_fe_sqrt_ratio_i, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
+    });
+}
+
+// ---- Scalar
+int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, a, b, o, n, 40); }
+int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, a, b, o, n, 40); }
+int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, a, b, o, n, 40); }
+int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40); }
+int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40); }
+int zc_sc_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
+{
+    REQUIRE(in32); REQUIRE(out);
+    Arg args[3] = {in_arg(in32, 32), out_arg(out, 40), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_from_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], 1, cnt);
+    });
+}
+int zc_sc_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n) { return zc_fe_to_bytes(ctx, in, out32, n); }
+
+// ---- EdwardsPoint
+int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, p, q, o, n, 160); }
+int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, p, q, o, n, 160); }
+int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160); }
+int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160); }
+
+int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
+{
+    if (flags != ZC_SCALAR_MUL_STRICT) return fail(ZC_ERR_BAD_ARG, "unknown scalar_mul flags");
+    return scalar_mul_impl(ctx, p, k, false, out, n);
+}
+int zc_ed_mul_by_pow_2(zc_ctx* ctx, const uint64_t* p, uint64_t kexp, uint64_t* out, size_t n)
+{
+    if (kexp >= 250) return fail(ZC_ERR_BAD_ARG, "Exponent can't be greater than the sub-group order");   // scalar.rs:531
+    uint64_t k[5] = {0, 0, 0, 0, 0};
+    k[kexp / 52] = 1ull << (kexp % 52);                  // Scalar::two_pow_k, scalar.rs:525-552
+    // the broadcast scalar is a host value: route it through a tiny device copy when p is on device
+    Residency r = RES_HOST;
+    int d = -1;
+    if (p) residency_of(p, &r, &d);
+    if (r == RES_DEVICE) {
+        if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+        DevState* ds = nullptr;
+        for (auto& x : ctx->devs)
+            if (x.device == d) ds = &x;
+        if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            HIP_TRY(hipSetDevice(ds->device));
+            int rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], 64);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(ds->tmp[1], k, 40, hipMemcpyHostToDevice, ds->s()));
+            HIP_TRY(hipStreamSynchronize(ds->s()));       // k[] is a stack buffer
+        }
+        return scalar_mul_impl(ctx, p, (const uint64_t*)ds->tmp[1], true, out, n);
+    }
+    return scalar_mul_impl(ctx, p, k, true, out, n);
+}
+int zc_ed_mul_by_cofactor(zc_ctx* ctx, const uint64_t* p, uint64_t* out, size_t n)
+{
+    return zc_ed_mul_by_pow_2(ctx, p, 3, out, n);         // Scalar::from(8u8), edwards.rs:174-179
+}
+int zc_ed_to_affine(zc_ctx* ctx, const uint64_t* p, uint64_t* xy, uint8_t* ok, size_t n)
+{
+    REQUIRE(p); REQUIRE(xy);
+    Arg args[3] = {in_arg(p, 160), out_arg(xy, 80), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_ed_eq(zc_ctx* ctx, const uint64_t* p, const uint64_t* q, uint8_t* eq, size_t n)
+{
+    REQUIRE(p); REQUIRE(q); REQUIRE(eq);
+    Arg args[3] = {in_arg(p, 160), in_arg(q, 160), out_arg(eq, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ed_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_ed_compress(zc_ctx* ctx, const uint64_t* p, uint8_t* out32, uint8_t* ok, size_t n)
+{
+    REQUIRE(p); REQUIRE(out32);
+    Arg args[3] = {in_arg(p, 160), out_arg(out32, 32), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ed_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (uint8_t*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_ed_decompress(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
+{
+    REQUIRE(in32); REQUIRE(out);
+    Arg args[3] = {in_arg(in32, 32), out_arg(out, 160), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ed_decompress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+
+// ---- Ristretto
+int zc_ris_compress(zc_ctx* ctx, const uint64_t* p, uint8_t* out32, size_t n)
+{
+    REQUIRE(p); REQUIRE(out32);
+    Arg args[2] = {in_arg(p, 160), out_arg(out32, 32)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ris_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_ris_decompress(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
+{
+    REQUIRE(in32); REQUIRE(out);
+    Arg args[3] = {in_arg(in32, 32), out_arg(out, 160), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ris_decompress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_ris_eq(zc_ctx* ctx, const uint64_t* p, const uint64_t* q, uint8_t* eq, size_t n)
+{
+    REQUIRE(p); REQUIRE(q); REQUIRE(eq);
+    Arg args[3] = {in_arg(p, 160), in_arg(q, 160), out_arg(eq, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ris_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, uint8_t* out32, uint8_t* ok, size_t n)
+{
+    REQUIRE(in32); REQUIRE(k); REQUIRE(out32);
+    Arg args[4] = {in_arg(in32, 32), in_arg(k, 40), out_arg(out32, 32), out_arg(ok, 1)};
+    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, hipStream_t s) {
+        hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], cnt);
+    });
+}
+
+// ---- MSM: sum_i k_i * P_i.  Round-1 realisation: per-GPU batched scalar-mul into a
+// partial array, log2(n) pairwise folds with the unified add, then the per-device
+// partials are folded in device order on device 0.  (A bucket method replaces the
+// first stage later; the result is compared as a group element.)
+int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out_point)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(points); REQUIRE(scalars); REQUIRE(out_point);
+    static const uint64_t ident[20] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (n == 0) {
+        memcpy(out_point, ident, sizeof ident);
+        return ZC_OK;
+    }
+    Residency rp, rk;
+    int dp = -1, dk = -1;
+    residency_of(points, &rp, &dp);
+    residency_of(scalars, &rk, &dk);
+    if (rp != rk || (rp == RES_DEVICE && dp != dk)) return fail(ZC_ERR_MIXED_MEM, "points/scalars residency differs");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+
+    std::vector<uint64_t> partials;
+    size_t ndev = (rp == RES_DEVICE) ? 1 : ctx->devs.size();
+    const size_t per = (n + ndev - 1) / ndev;
+    std::vector<DevState*> used;
+    for (size_t di = 0; di < ndev; di++) {
+        const size_t lo = di * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        const size_t cnt = hi - lo;
+        DevState* ds = nullptr;
+        if (rp == RES_DEVICE) {
+            for (auto& x : ctx->devs)
+                if (x.device == dp) ds = &x;
+            if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+        } else {
+            ds = &ctx->devs[di];
+        }
+        HIP_TRY(hipSetDevice(ds->device));
+        const u64 *dP, *dK;
+        if (rp == RES_DEVICE) {
+            dP = points;
+            dK = scalars;
+        } else {
+            int rc = ensure(&ds->scratch[0], &ds->scratch_bytes[0], cnt * 160);
+            if (rc) return rc;
+            rc = ensure(&ds->scratch[1], &ds->scratch_bytes[1], cnt * 40);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(ds->scratch[0], points + 20 * lo, cnt * 160, hipMemcpyHostToDevice, ds->s()));
+            HIP_TRY(hipMemcpyAsync(ds->scratch[1], scalars + 5 * lo, cnt * 40, hipMemcpyHostToDevice, ds->s()));
+            dP = (const u64*)ds->scratch[0];
+            dK = (const u64*)ds->scratch[1];
+        }
+        int rc = ensure(&ds->tmp[0], &ds->tmp_bytes[0], cnt * 160);
+        if (rc) return rc;
+        rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], ((cnt + 1) / 2) * 160 + 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ds->s(), dP, dK, (size_t)5, (u64*)ds->tmp[0], cnt);
+        HIP_TRY(hipGetLastError());
+        used.push_back(ds);
+    }
+    // fold per device (ping-pong between tmp[0] and tmp[1])
+    partials.resize(used.size() * 20);
+    for (size_t ui = 0; ui < used.size(); ui++) {
+        DevState* ds = used[ui];
+        const size_t lo = ui * per, hi = std::min(n, lo + per);
+        size_t cnt = hi - lo;
+        HIP_TRY(hipSetDevice(ds->device));
+        int cur = 0;
+        while (cnt > 1) {
+            hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for((cnt + 1) / 2)), dim3(zc::ZC_BLOCK), 0, ds->s(),
+                               (const u64*)ds->tmp[cur], (u64*)ds->tmp[cur ^ 1], cnt);
+            HIP_TRY(hipGetLastError());
+            cnt = (cnt + 1) / 2;
+            cur ^= 1;
+        }
+        HIP_TRY(hipMemcpyAsync(partials.data() + 20 * ui, ds->tmp[cur], 160, hipMemcpyDeviceToHost, ds->s()));
+    }
+    for (DevState* ds : used) {
+        HIP_TRY(hipSetDevice(ds->device));
+        HIP_TRY(hipStreamSynchronize(ds->s()));
+    }
+    // fold the per-device partials in device order on the first device
+    size_t cnt = used.size();
+    if (cnt > 1) {
+        DevState* ds = used[0];
+        HIP_TRY(hipSetDevice(ds->device));
+        HIP_TRY(hipMemcpyAsync(ds->tmp[0], partials.data(), cnt * 160, hipMemcpyHostToDevice, ds->s()));
+        int cur = 0;
+        while (cnt > 1) {
+            hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for((cnt + 1) / 2)), dim3(zc::ZC_BLOCK), 0, ds->s(),
+                               (const u64*)ds->tmp[cur], (u64*)ds->tmp[cur ^ 1], cnt);
+            HIP_TRY(hipGetLastError());
+            cnt = (cnt + 1) / 2;
+            cur ^= 1;
+        }
+        HIP_TRY(hipMemcpyAsync(partials.data(), ds->tmp[cur], 160, hipMemcpyDeviceToHost, ds->s()));
+        HIP_TRY(hipStreamSynchronize(ds->s()));
+    }
+    memcpy(out_point, partials.data(), 160);
+    return ZC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+"""Batch engine: the host-side mirror of zerocaf's field / scalar / edwards / ristretto
+operator surface over the C ABI (include/zerocaf_hip.h).
+
+Arrays use the reference's in-memory layout: FieldElement / Scalar = (n, 5) uint64 limbs
+(radix 2^52), EdwardsPoint = (n, 20) uint64 (X|Y|Z|T), encodings = (n, 32) uint8.
+Inputs may be numpy arrays (host memory: staged over PCIe by the library) or torch CUDA
+tensors (device memory: used in place on the engine's stream, asynchronous).  Outputs are
+of the same kind as the first input.  All arithmetic runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+STRICT = 0
+
+
+def _is_torch(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "device")
+
+
+class Engine:
+    """One zc_ctx.  `devices=None` uses the current HIP device."""
+
+    def __init__(self, devices=None):
+        self.lib = _lib.load()
+        self.ctx = C.c_void_p()
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.zc_ctx_create(arr, len(devices), C.byref(self.ctx))
+        else:
+            rc = self.lib.zc_ctx_create(None, 0, C.byref(self.ctx))
+        _lib.check(rc, "zc_ctx_create")
+
+    def close(self):
+        if self.ctx:
+            self.lib.zc_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(stream_handle)), "zc_ctx_set_stream")
+
+    def synchronize(self):
+        _lib.check(self.lib.zc_ctx_synchronize(self.ctx), "zc_ctx_synchronize")
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _prep(x, width, dtype):
+        if _is_torch(x):
+            assert x.is_contiguous() and x.shape[-1] == width, (x.shape, width)
+            assert x.element_size() == np.dtype(dtype).itemsize
+            return x, x.data_ptr(), x.shape[0]
+        a = np.ascontiguousarray(x, dtype=dtype)
+        assert a.ndim == 2 and a.shape[1] == width, (a.shape, width)
+        return a, a.ctypes.data, a.shape[0]
+
+    @staticmethod
+    def _alloc(like, n, width, dtype):
+        if _is_torch(like):
+            import torch
+            tdt = torch.uint8 if np.dtype(dtype) == np.uint8 else like.dtype if like.element_size() == 8 else torch.int64
+            shape = (n, width) if width else (n,)
+            t = torch.empty(shape, dtype=tdt, device=like.device)
+            return t, t.data_ptr()
+        shape = (n, width) if width else (n,)
+        a = np.empty(shape, dtype=dtype)
+        return a, a.ctypes.data
+
+    def _call(self, name, *args):
+        _lib.check(getattr(self.lib, name)(self.ctx, *args), name)
+
+    def _bin(self, name, a, b, w):
+        a, pa, n = self._prep(a, w, np.uint64)
+        b, pb, nb = self._prep(b, w, np.uint64)
+        assert n == nb
+        out, po = self._alloc(a, n, w, np.uint64)
+        self._call(name, pa, pb, po, n)
+        return out
+
+    def _un(self, name, a, w):
+        a, pa, n = self._prep(a, w, np.uint64)
+        out, po = self._alloc(a, n, w, np.uint64)
+        self._call(name, pa, po, n)
+        return out
+
+    # ------------------------------------------------------------------ FieldElement (field.rs)
+    def fe_add(self, a, b): return self._bin("zc_fe_add", a, b, 5)
+    def fe_sub(self, a, b): return self._bin("zc_fe_sub", a, b, 5)
+    def fe_mul(self, a, b): return self._bin("zc_fe_mul", a, b, 5)
+    def fe_neg(self, a): return self._un("zc_fe_neg", a, 5)
+    def fe_square(self, a): return self._un("zc_fe_square", a, 5)
+
+    def fe_invert(self, a):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 5, np.uint64)
+        ok, pk = self._alloc(a, n, 0, np.uint8)
+        self._call("zc_fe_invert", pa, po, pk, n)
+        return out, ok
+
+    def fe_from_bytes(self, b):
+        b, pb, n = self._prep(b, 32, np.uint8)
+        out, po = self._alloc_u64(b, n, 5)
+        self._call("zc_fe_from_bytes", pb, po, n)
+        return out
+
+    def fe_to_bytes(self, a):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 32, np.uint8)
+        self._call("zc_fe_to_bytes", pa, po, n)
+        return out
+
+    def fe_sqrt_ratio_i(self, u, v):
+        u, pu, n = self._prep(u, 5, np.uint64)
+        v, pv, _ = self._prep(v, 5, np.uint64)
+        out, po = self._alloc(u, n, 5, np.uint64)
+        sq, ps = self._alloc(u, n, 0, np.uint8)
+        self._call("zc_fe_sqrt_ratio_i", pu, pv, po, ps, n)
+        return out, sq
+
+    def _alloc_u64(self, like, n, width):
+        if _is_torch(like):
+            import torch
+            t = torch.empty((n, width), dtype=torch.int64, device=like.device)
+            return t, t.data_ptr()
+        a = np.empty((n, width), dtype=np.uint64)
+        return a, a.ctypes.data
+
+    # ------------------------------------------------------------------ Scalar (scalar.rs)
+    def sc_add(self, a, b): return self._bin("zc_sc_add", a, b, 5)
+    def sc_sub(self, a, b): return self._bin("zc_sc_sub", a, b, 5)
+    def sc_mul(self, a, b): return self._bin("zc_sc_mul", a, b, 5)
+    def sc_neg(self, a): return self._un("zc_sc_neg", a, 5)
+    def sc_square(self, a): return self._un("zc_sc_square", a, 5)
+
+    def sc_from_bytes(self, b):
+        b, pb, n = self._prep(b, 32, np.uint8)
+        out, po = self._alloc_u64(b, n, 5)
+        ok, pk = self._alloc(b, n, 0, np.uint8)
+        self._call("zc_sc_from_bytes", pb, po, pk, n)
+        return out, ok
+
+    def sc_to_bytes(self, a):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 32, np.uint8)
+        self._call("zc_sc_to_bytes", pa, po, n)
+        return out
+
+    # ------------------------------------------------------------------ EdwardsPoint (edwards.rs)
+    def ed_add(self, p, q): return self._bin("zc_ed_add", p, q, 20)
+    def ed_sub(self, p, q): return self._bin("zc_ed_sub", p, q, 20)
+    def ed_double(self, p): return self._un("zc_ed_double", p, 20)
+    def ed_neg(self, p): return self._un("zc_ed_neg", p, 20)
+
+    def ed_scalar_mul(self, p, k, out=None, flags=STRICT):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        k, pk, nk = self._prep(k, 5, np.uint64)
+        assert n == nk
+        if out is None:
+            out, po = self._alloc(p, n, 20, np.uint64)
+        else:
+            out, po, _ = self._prep(out, 20, np.uint64)
+        self._call("zc_ed_scalar_mul", pp, pk, po, n, flags)
+        return out
+
+    def ed_mul_by_pow_2(self, p, kexp):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        out, po = self._alloc(p, n, 20, np.uint64)
+        self._call("zc_ed_mul_by_pow_2", pp, C.c_uint64(kexp), po, n)
+        return out
+
+    def ed_mul_by_cofactor(self, p):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        out, po = self._alloc(p, n, 20, np.uint64)
+        self._call("zc_ed_mul_by_cofactor", pp, po, n)
+        return out
+
+    def ed_to_affine(self, p):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        xy, px = self._alloc(p, n, 10, np.uint64)
+        ok, pk = self._alloc(p, n, 0, np.uint8)
+        self._call("zc_ed_to_affine", pp, px, pk, n)
+        return xy, ok
+
+    def ed_eq(self, p, q):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        q, pq, _ = self._prep(q, 20, np.uint64)
+        eq, pe = self._alloc(p, n, 0, np.uint8)
+        self._call("zc_ed_eq", pp, pq, pe, n)
+        return eq
+
+    def ed_compress(self, p):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        out, po = self._alloc(p, n, 32, np.uint8)
+        ok, pk = self._alloc(p, n, 0, np.uint8)
+        self._call("zc_ed_compress", pp, po, pk, n)
+        return out, ok
+
+    def ed_decompress(self, b):
+        b, pb, n = self._prep(b, 32, np.uint8)
+        out, po = self._alloc_u64(b, n, 20)
+        ok, pk = self._alloc(b, n, 0, np.uint8)
+        self._call("zc_ed_decompress", pb, po, pk, n)
+        return out, ok
+
+    # ------------------------------------------------------------------ Ristretto (ristretto.rs)
+    def ris_compress(self, p):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        out, po = self._alloc(p, n, 32, np.uint8)
+        self._call("zc_ris_compress", pp, po, n)
+        return out
+
+    def ris_decompress(self, b):
+        b, pb, n = self._prep(b, 32, np.uint8)
+        out, po = self._alloc_u64(b, n, 20)
+        ok, pk = self._alloc(b, n, 0, np.uint8)
+        self._call("zc_ris_decompress", pb, po, pk, n)
+        return out, ok
+
+    def ris_eq(self, p, q):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        q, pq, _ = self._prep(q, 20, np.uint64)
+        eq, pe = self._alloc(p, n, 0, np.uint8)
+        self._call("zc_ris_eq", pp, pq, pe, n)
+        return eq
+
+    def ris_roundtrip_mul(self, b, k, out=None):
+        b, pb, n = self._prep(b, 32, np.uint8)
+        k, pk, _ = self._prep(k, 5, np.uint64)
+        if out is None:
+            out, po = self._alloc(b, n, 32, np.uint8)
+        else:
+            out, po, _ = self._prep(out, 32, np.uint8)
+        ok, pko = self._alloc(b, n, 0, np.uint8)
+        self._call("zc_ris_roundtrip_mul", pb, pk, po, pko, n)
+        return out, ok
+
+    # ------------------------------------------------------------------ MSM (not in the reference)
+    def msm(self, points, scalars):
+        points, pp, n = self._prep(points, 20, np.uint64)
+        scalars, pk, _ = self._prep(scalars, 5, np.uint64)
+        out = np.empty((1, 20), dtype=np.uint64)
+        self._call("zc_msm", pp, pk, n, out.ctypes.data)
+        return out

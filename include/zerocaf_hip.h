@@ -1,0 +1,140 @@
+/*
+ * zerocaf_hip.h -- C ABI of libzerocaf_hip.so: the batched MI355X (gfx950) backend
+ * for dusk-zerocaf's hot path (FieldElement / Scalar / EdwardsPoint / Ristretto
+ * arithmetic on the Sonny/Doppio curve).
+ *
+ * The reference (crate `zerocaf`, pure Rust) has no FFI and no batch API; its
+ * path sits behind operator traits on `Copy` structs.  Each entry point below is
+ * the batched form of one reference operation, cited as file:line relative to the
+ * reference checkout, and is what a thin Rust `extern "C"` shim binds (see
+ * INTEGRATION.md).  Results are bit-identical to the reference on canonical
+ * inputs (limbs < 2^52, value < modulus); Scalar operands of scalar-mul may be any
+ * 5x52-bit pattern (treated as a plain integer, as double_and_add does).
+ *
+ * Data layout (all arrays contiguous, caller-owned, array-of-structs exactly as
+ * the reference's in-memory limbs):
+ *   FieldElement / Scalar : 5 x uint64  (radix 2^52, little-endian limbs)   40 B
+ *   EdwardsPoint          : X | Y | Z | T = 20 x uint64                      160 B
+ *   affine point          : x | y = 10 x uint64                              80 B
+ *   compressed encodings  : 32 bytes
+ * Every pointer may be HOST memory or DEVICE (HIP) memory; the library detects
+ * which.  Host buffers are staged over PCIe and the call returns when results are
+ * in the caller's buffer.  Device buffers are used in place: the kernels are
+ * enqueued on the context's stream and the call returns immediately -- order
+ * later work on the same stream or call zc_ctx_synchronize().
+ *
+ * Return value: 0 on success, negative zc_status on error.  Where the reference
+ * panics or returns None for an individual element (inverse of 0, undecodable
+ * point, scalar bytes > L-1), the optional `ok` mask gets 0 for that element (1
+ * otherwise), the output element is zero/identity, and the call still succeeds.
+ * All functions are thread-safe per context (one context per thread or external
+ * locking); there is NO CPU fallback: without a usable GPU every call fails with
+ * ZC_ERR_NO_DEVICE.
+ */
+#ifndef ZEROCAF_HIP_H
+#define ZEROCAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zc_ctx zc_ctx;
+
+typedef enum zc_status {
+    ZC_OK = 0,
+    ZC_ERR_BAD_ARG = -1,     /* null pointer, bad exponent (reference: assert!/panic) */
+    ZC_ERR_NO_DEVICE = -2,   /* no HIP device visible */
+    ZC_ERR_HIP = -3,         /* HIP runtime error; see zc_last_error() */
+    ZC_ERR_NOMEM = -4,
+    ZC_ERR_MIXED_MEM = -5    /* buffers of one call live on different devices */
+} zc_status;
+
+#define ZC_SCALAR_MUL_STRICT 0u  /* reference formula sequence: (X:Y:Z:T) limbs identical */
+
+/* ---- context -------------------------------------------------------------- */
+/* devices == NULL / ndev == 0: use the current HIP device.  With ndev > 1, calls on
+ * HOST buffers shard the batch into ndev contiguous ranges (independent
+ * elements, no exchange step).                                                  */
+int zc_ctx_create(const int *devices, int ndev, zc_ctx **out);
+int zc_ctx_destroy(zc_ctx *ctx);
+/* Borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for
+ * device 0 of the context; NULL restores the context's own stream.             */
+int zc_ctx_set_stream(zc_ctx *ctx, void *hip_stream);
+int zc_ctx_synchronize(zc_ctx *ctx);
+int zc_device_count(void);
+const char *zc_last_error(void);
+const char *zc_version(void);
+
+/* ---- FieldElement (mod p = 2^252 + 27742317777372353535851937790883648493) --- */
+/* Add: src/backend/u64/field.rs:191-207   Sub: :217-240   Neg: :170-189         */
+int zc_fe_add(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int zc_fe_sub(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int zc_fe_neg(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+/* Mul: field.rs:250-275 (mul_internal :741-757 + montgomery_reduce :780-813, twice) */
+int zc_fe_mul(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* Square: field.rs:302-315 (square_internal :763-777) */
+int zc_fe_square(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+/* inverse: field.rs:854-925 (panics on 0 -> ok[i] = 0, out = 0) */
+int zc_fe_invert(zc_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *ok, size_t n);
+/* from_bytes: field.rs:563-587   to_bytes: :591-631 */
+int zc_fe_from_bytes(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, size_t n);
+int zc_fe_to_bytes(zc_ctx *ctx, const uint64_t *in, uint8_t *out32, size_t n);
+/* SqrtRatioI: field.rs:462-503 (InvSqrt :443-460 is u = 1) */
+int zc_fe_sqrt_ratio_i(zc_ctx *ctx, const uint64_t *u, const uint64_t *v, uint64_t *out,
+                       uint8_t *was_square, size_t n);
+
+/* ---- Scalar (mod L = 2^249 + 14490550575682688738086195780655237219) --------- */
+/* Add: src/backend/u64/scalar.rs:184-200  Sub: :210-237  Neg: :139-155          */
+int zc_sc_add(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int zc_sc_sub(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int zc_sc_neg(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+/* Mul: scalar.rs:247-270 (Montgomery path :580-652)   Square: :272-283 */
+int zc_sc_mul(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int zc_sc_square(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+/* from_bytes: scalar.rs:445-467 (asserts <= L-1 -> ok[i] = 0)   to_bytes: :477-516 */
+int zc_sc_from_bytes(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, uint8_t *ok, size_t n);
+int zc_sc_to_bytes(zc_ctx *ctx, const uint64_t *in, uint8_t *out32, size_t n);
+
+/* ---- EdwardsPoint ------------------------------------------------------------ */
+/* Add: src/edwards.rs:465-501   Sub: :503-545   Double: :579-592 (= add)   Neg: :440-463 */
+int zc_ed_add(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
+int zc_ed_sub(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
+int zc_ed_double(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+int zc_ed_neg(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+/* Mul<Scalar> = double_and_add: edwards.rs:102-120, :547-577.  k: n scalars (5 x u64) */
+int zc_ed_scalar_mul(zc_ctx *ctx, const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n,
+                     unsigned flags);
+/* mul_by_pow_2: edwards.rs:186-191 (kexp >= 250 -> ZC_ERR_BAD_ARG, reference asserts)
+ * mul_by_cofactor: :174-179                                                        */
+int zc_ed_mul_by_pow_2(zc_ctx *ctx, const uint64_t *p, uint64_t kexp, uint64_t *out, size_t n);
+int zc_ed_mul_by_cofactor(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+/* AffinePoint::from: edwards.rs:1071-1092 (Z == 0 -> ok = 0)   ==: :360-370 */
+int zc_ed_to_affine(zc_ctx *ctx, const uint64_t *p, uint64_t *xy_out, uint8_t *ok, size_t n);
+int zc_ed_eq(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint8_t *eq_out, size_t n);
+/* compress: edwards.rs:613-629   decompress: :313-326 (None -> ok = 0, out = identity) */
+int zc_ed_compress(zc_ctx *ctx, const uint64_t *p, uint8_t *out32, uint8_t *ok, size_t n);
+int zc_ed_decompress(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, uint8_t *ok, size_t n);
+
+/* ---- Ristretto ----------------------------------------------------------------- */
+/* compress: src/ristretto.rs:398-425   decompress: :96-154   ct_eq: :166-176 */
+int zc_ris_compress(zc_ctx *ctx, const uint64_t *p, uint8_t *out32, size_t n);
+int zc_ris_decompress(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, uint8_t *ok, size_t n);
+int zc_ris_eq(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint8_t *eq_out, size_t n);
+/* fused decompress -> Mul<Scalar> -> compress (ristretto.rs:96-154, :330-392, :398-425);
+ * undecodable input -> ok = 0, out32 = 0                                           */
+int zc_ris_roundtrip_mul(zc_ctx *ctx, const uint8_t *in32, const uint64_t *k, uint8_t *out32,
+                         uint8_t *ok, size_t n);
+
+/* ---- multi-scalar multiplication (not in the reference: sum_i k_i * P_i) -------- */
+/* out_point: one EdwardsPoint (HOST memory), equal to the reference's
+ * sum of `&P_i * &k_i` as a group element (compare with ==, i.e. affine/compressed). */
+int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
+           uint64_t *out_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZEROCAF_HIP_H */

@@ -1,0 +1,143 @@
+// emul.cpp -- TEST-ONLY host build of the device arithmetic headers.
+// Compiles dusk_zerocaf_amd/csrc/zc_arith.cuh + zc_curve.cuh with g++ (the HIP
+// qualifiers expand to nothing under a non-HIP compiler) so the exact limb
+// algorithms the kernels run can be checked against the oracle in the CPU-only
+// test tier, before any GPU time is spent.  Never shipped, never loaded by
+// dusk_zerocaf_amd/: the product path has no CPU fallback.
+#include <cstddef>
+#include <cstdint>
+#include "../../dusk_zerocaf_amd/csrc/zc_curve.cuh"
+
+using namespace zc;
+
+static pt scalar_mul_seq(const pt& P, const u64 (&l)[5])
+{
+    // same op sequence as scalar_mul_unified (zc_kernels.cuh), one lane
+    u32 w[9];
+    for (int k = 0; k < 9; k++) {
+        const int bit = 32 * k, idx = bit / 52, sh = bit % 52;
+        u64 x = (idx < 5) ? ((l[idx] & M52) >> sh) : 0;
+        if (sh + 32 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
+        w[k] = (u32)x;
+    }
+    w[8] &= 0xFu;
+    int nbits = 0;
+    for (int k = 0; k < 9; k++)
+        if (w[k]) nbits = 32 * k + (32 - __builtin_clz(w[k]));
+    pt N = P, Q = pt_identity();
+    int pos = 0;
+    bool pend = (w[0] & 1) != 0;
+    bool active = nbits > 0;
+    while (active) {
+        const pt lhs = pt_select(pend, Q, N);
+        const pt r = pt_add(lhs, N);
+        if (pend) { Q = r; pend = false; active = pos < nbits - 1; }
+        else { N = r; pos++; pend = ((w[pos >> 5] >> (pos & 31)) & 1) != 0; }
+    }
+    return Q;
+}
+
+template <class F>
+static void store_plain(u64* o, const fe& x)
+{
+    u64 l[5];
+    fe_to_limbs52(l, fe_cond_sub_n<F>(fe_cond_sub_n<F>(x)));
+    for (int i = 0; i < 5; i++) o[i] = l[i];
+}
+static void ld5(u64 (&l)[5], const u64* p) { for (int i = 0; i < 5; i++) l[i] = p[i]; }
+
+extern "C" {
+void emul_fe_mul(const u64* a, const u64* b, u64* out, size_t n, int modl)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 x[5], y[5];
+        ld5(x, a + 5 * i); ld5(y, b + 5 * i);
+        if (modl) store_plain<ModL>(out + 5 * i, mont_mul<ModL>(mont_to<ModL>(fe_from_limbs52(x)), fe_from_limbs52(y)));
+        else store_plain<ModP>(out + 5 * i, mont_mul<ModP>(mont_to<ModP>(fe_from_limbs52(x)), fe_from_limbs52(y)));
+    }
+}
+void emul_fe_square(const u64* a, u64* out, size_t n, int modl)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 x[5];
+        ld5(x, a + 5 * i);
+        if (modl) store_plain<ModL>(out + 5 * i, mont_mul<ModL>(mont_sqr<ModL>(fe_from_limbs52(x)), fe_const<ModL>(ModL::RR)));
+        else store_plain<ModP>(out + 5 * i, mont_mul<ModP>(mont_sqr<ModP>(fe_from_limbs52(x)), fe_const<ModP>(ModP::RR)));
+    }
+}
+void emul_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        const fe x = fe_load_mont<FP>(a + 5 * i);
+        ok[i] = !fp_is_zero(x);
+        fe_store_canon<FP>(out + 5 * i, fp_invert(x));
+    }
+}
+void emul_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* sq, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        fe r;
+        sq[i] = fp_sqrt_ratio_i(r, fe_load_mont<FP>(u + 5 * i), fe_load_mont<FP>(v + 5 * i));
+        fe_store_canon<FP>(out + 5 * i, r);
+    }
+}
+void emul_ed_add(const u64* p, const u64* q, u64* out, size_t n)
+{ for (size_t i = 0; i < n; i++) pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_load(q + 20 * i))); }
+void emul_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
+{ for (size_t i = 0; i < n; i++) pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_neg(pt_load(q + 20 * i)))); }
+void emul_ed_scalar_mul(const u64* p, const u64* k, u64* out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 l[5];
+        ld5(l, k + 5 * i);
+        pt_store(out + 20 * i, scalar_mul_seq(pt_load(p + 20 * i), l));
+    }
+}
+void emul_ed_to_affine(const u64* p, u64* xy, uint8_t* ok, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        fe x, y;
+        ok[i] = ed_to_affine(x, y, pt_load(p + 20 * i));
+        fe_store_canon<FP>(xy + 10 * i, x);
+        fe_store_canon<FP>(xy + 10 * i + 5, y);
+    }
+}
+void emul_ed_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
+{ for (size_t i = 0; i < n; i++) eq[i] = ed_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)); }
+void emul_ed_compress(const u64* p, u64* out32, uint8_t* ok, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 w[4];
+        ok[i] = ed_compress(w, pt_load(p + 20 * i));
+        for (int j = 0; j < 4; j++) out32[4 * i + j] = ok[i] ? w[j] : 0;
+    }
+}
+void emul_ed_decompress(const u64* in32, u64* out, uint8_t* ok, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 w[4] = {in32[4 * i], in32[4 * i + 1], in32[4 * i + 2], in32[4 * i + 3]};
+        pt r;
+        ok[i] = ed_decompress(r, w);
+        pt_store(out + 20 * i, pt_select(ok[i], r, pt_identity()));
+    }
+}
+void emul_ris_compress(const u64* p, u64* out32, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 w[4];
+        fe_to_words256(w, ris_compress(pt_load(p + 20 * i)));
+        for (int j = 0; j < 4; j++) out32[4 * i + j] = w[j];
+    }
+}
+void emul_ris_decompress(const u64* in32, u64* out, uint8_t* ok, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 w[4] = {in32[4 * i], in32[4 * i + 1], in32[4 * i + 2], in32[4 * i + 3]};
+        pt r;
+        ok[i] = ris_decompress(r, w);
+        pt_store(out + 20 * i, pt_select(ok[i], r, pt_identity()));
+    }
+}
+void emul_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
+{ for (size_t i = 0; i < n; i++) eq[i] = ris_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)); }
+}

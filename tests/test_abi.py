@@ -1,0 +1,58 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/zerocaf_hip.h declares
+(no compute without a GPU), and refuses to work without a device instead of falling back."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "zerocaf_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zc_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import dusk_zerocaf_amd as z
+    if not os.path.exists(z.LIB_PATH):
+        from dusk_zerocaf_amd import build
+        build.build()
+    return z.load()
+
+
+def test_header_declares_the_path():
+    syms = declared_symbols()
+    for must in ("zc_fe_mul", "zc_fe_square", "zc_fe_invert", "zc_sc_mul", "zc_ed_add", "zc_ed_double",
+                 "zc_ed_scalar_mul", "zc_ed_mul_by_pow_2", "zc_ed_compress", "zc_ed_decompress",
+                 "zc_ris_compress", "zc_ris_decompress", "zc_ris_roundtrip_mul", "zc_msm"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    import dusk_zerocaf_amd as z
+    syms = declared_symbols()
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(z.ALL_SYMBOLS) == syms                 # the ctypes table mirrors the header exactly
+    out = subprocess.check_output(["nm", "-D", "--defined-only", z.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (zc_[a-z0-9_]+)", out))
+    assert set(syms) <= exported
+
+
+def test_no_cpu_fallback_and_no_oracle_linkage(lib):
+    import dusk_zerocaf_amd as z
+    out = subprocess.check_output(["nm", "-D", z.LIB_PATH], text=True)
+    assert "zr_" not in out                              # nothing from oracle/ is linked in
+    if lib.zc_device_count() == 0:
+        with pytest.raises(z.ZerocafHipError):
+            z.Engine()                                   # fails loudly: status ZC_ERR_NO_DEVICE
+    for root, _, files in os.walk(os.path.join(ROOT, "dusk_zerocaf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "zc_ref" not in src and "from oracle" not in src and "import oracle" not in src, f

@@ -1,0 +1,139 @@
+"""CPU tier: the device arithmetic headers (radix-2^29 Montgomery, unified-step scalar
+multiplication, one-exponentiation codecs), compiled for the host with g++ by
+tests/emul/, must agree bit-for-bit with the oracle.  This checks the kernels' limb
+algorithms before any GPU time is spent; it is not a CPU fallback (nothing in
+dusk_zerocaf_amd/ can reach it)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pymodel as pm
+from tests import vectors as V
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, "emul")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(EMUL_DIR, "libzc_emul.so")
+    src = os.path.join(EMUL_DIR, "emul.cpp")
+    csrc = os.path.join(os.path.dirname(HERE), "dusk_zerocaf_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("zc_arith.cuh", "zc_curve.cuh", "zc_constants.cuh")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        inc = "/opt/rocm/include"
+        if not os.path.isdir(inc):
+            pytest.skip("ROCm headers not present")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+                               "-I" + inc, "-o", so, src])
+    return C.CDLL(so)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_emul_mul_square(emul, oracle):
+    for modl, mod, orc_mul, orc_sq, edge in ((0, pm.P, oracle.fe_mul, oracle.fe_square, V.FE_EDGE),
+                                             (1, pm.L, oracle.sc_mul, oracle.sc_square, V.SC_EDGE)):
+        a = V.limbs_array(V.rand_fe(4000, V.SEED + 1, mod, edge))
+        b = V.limbs_array(list(reversed(V.rand_fe(4000, V.SEED + 2, mod, edge))))
+        out = np.empty_like(a)
+        emul.emul_fe_mul(p(a), p(b), p(out), C.c_size_t(len(a)), modl)
+        assert np.array_equal(out, orc_mul(a, b))
+        emul.emul_fe_square(p(a), p(out), C.c_size_t(len(a)), modl)
+        assert np.array_equal(out, orc_sq(a))
+    # non-canonical operands with limbs < 2^52 are value-correct too
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 1 << 52, size=(500, 5), dtype=np.uint64)
+    b = rng.integers(0, 1 << 52, size=(500, 5), dtype=np.uint64)
+    out = np.empty_like(a)
+    emul.emul_fe_mul(p(a), p(b), p(out), C.c_size_t(500), 0)
+    assert np.array_equal(out, oracle.fe_mul(a, b))
+
+
+def test_emul_invert_sqrt_ratio(emul, oracle):
+    a = V.limbs_array(V.rand_fe(200, V.SEED + 3))
+    out, ok = np.empty_like(a), np.empty(len(a), dtype=np.uint8)
+    emul.emul_fe_invert(p(a), p(out), p(ok), C.c_size_t(len(a)))
+    want, wok = oracle.fe_invert(a)
+    assert np.array_equal(ok, wok) and np.array_equal(out, want)
+    u = V.limbs_array(V.rand_fe(120, V.SEED + 4))
+    v = V.limbs_array(list(reversed(V.rand_fe(120, V.SEED + 5))))
+    sq = np.empty(len(u), dtype=np.uint8)
+    emul.emul_fe_sqrt_ratio_i(p(u), p(v), p(out[:120]), p(sq), C.c_size_t(120))
+    want, wsq = oracle.fe_sqrt_ratio_i(u, v)
+    assert np.array_equal(sq, wsq) and np.array_equal(out[:120], want)
+
+
+def test_emul_point_ops(emul, oracle):
+    n = 48
+    P = V.base_multiples(oracle, n, V.SEED + 6)
+    Q = V.base_multiples(oracle, n, V.SEED + 7)
+    P[0] = V.IDENT_ROW
+    Q[1] = V.IDENT_ROW
+    Q[2] = P[2]
+    out = np.empty_like(P)
+    emul.emul_ed_add(p(P), p(Q), p(out), C.c_size_t(n))
+    assert np.array_equal(out, oracle.ed_add(P, Q))
+    emul.emul_ed_sub(p(P), p(Q), p(out), C.c_size_t(n))
+    assert np.array_equal(out, oracle.ed_sub(P, Q))
+    K = V.rand_scalars_np(n, V.SEED + 8, bits=252)
+    K[0] = 0
+    K[1] = [1, 0, 0, 0, 0]
+    K[2] = pm.limbs(pm.L)
+    K[3] = pm.limbs(2**249 - 1)
+    K[4] = [(1 << 52) - 1] * 4 + [(1 << 52) - 1]          # all 260 bits set (raw limb pattern)
+    K[5] = [0, 0, 0, 0, 1 << 47]
+    K[6] = pm.limbs(8)
+    emul.emul_ed_scalar_mul(p(P), p(K), p(out), C.c_size_t(n))
+    assert np.array_equal(out, oracle.ed_scalar_mul(P, K))   # strict (X:Y:Z:T) limbs
+    xy, ok = np.empty((n, 10), dtype=np.uint64), np.empty(n, dtype=np.uint8)
+    emul.emul_ed_to_affine(p(out), p(xy), p(ok), C.c_size_t(n))
+    wxy, wok = oracle.ed_to_affine(out)
+    assert np.array_equal(ok, wok) and np.array_equal(xy, wxy)
+    eq = np.empty(n, dtype=np.uint8)
+    emul.emul_ed_eq(p(P), p(Q), p(eq), C.c_size_t(n))
+    assert np.array_equal(eq, oracle.ed_eq(P, Q)) and eq[2] == 1 and eq[3] == 0
+
+
+def test_emul_codecs(emul, oracle):
+    n = 40
+    P = V.base_multiples(oracle, n, V.SEED + 9)
+    P[0] = V.IDENT_ROW
+    enc, ok = np.empty((n, 4), dtype=np.uint64), np.empty(n, dtype=np.uint8)
+    emul.emul_ed_compress(p(P), p(enc), p(ok), C.c_size_t(n))
+    wenc, wok = oracle.ed_compress(P)
+    assert np.array_equal(ok, wok) and np.array_equal(enc.view(np.uint8).reshape(n, 32), wenc)
+    dec = np.empty_like(P)
+    emul.emul_ed_decompress(p(enc), p(dec), p(ok), C.c_size_t(n))
+    wdec, wok = oracle.ed_decompress(wenc)
+    assert np.array_equal(ok, wok) and np.array_equal(dec, wdec)
+    renc = np.empty((n, 4), dtype=np.uint64)
+    emul.emul_ris_compress(p(P), p(renc), C.c_size_t(n))
+    wrenc = oracle.ris_compress(P)
+    assert np.array_equal(renc.view(np.uint8).reshape(n, 32), wrenc)
+    emul.emul_ris_decompress(p(renc), p(dec), p(ok), C.c_size_t(n))
+    wdec, wok = oracle.ris_decompress(wrenc)
+    assert np.array_equal(ok, wok) and np.array_equal(dec, wdec)
+    eq = np.empty(n, dtype=np.uint8)
+    emul.emul_ris_eq(p(P), p(dec), p(eq), C.c_size_t(n))
+    assert np.array_equal(eq, oracle.ris_eq(P, wdec)) and eq.all()
+    # random / invalid encodings: same accept mask and same points
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, size=(200, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x0F
+    raw[:3, 31] = 0xFF
+    rawq = np.ascontiguousarray(raw).view(np.uint64).reshape(200, 4)
+    dec = np.empty((200, 20), dtype=np.uint64)
+    ok = np.empty(200, dtype=np.uint8)
+    emul.emul_ris_decompress(p(rawq), p(dec), p(ok), C.c_size_t(200))
+    wdec, wok = oracle.ris_decompress(raw)
+    assert np.array_equal(ok, wok) and np.array_equal(dec, wdec) and 0 < ok.sum() < 200
+    raw[:3, 31] = 0x8F                                        # sign bit set, y bits masked by 0x0F
+    emul.emul_ed_decompress(p(rawq), p(dec), p(ok), C.c_size_t(200))
+    wdec, wok = oracle.ed_decompress(raw)
+    assert np.array_equal(ok, wok) and np.array_equal(dec, wdec) and 0 < ok.sum() < 200

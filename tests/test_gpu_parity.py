@@ -1,0 +1,309 @@
+"""GPU tier: the HIP path behind the C ABI (libzerocaf_hip.so) against the CPU oracle on
+the same seeded inputs -- bit-exact limbs / bytes / masks (integer work: no tolerance).
+Mirrors the reference's own unit tests where they exist (names in comments)."""
+import numpy as np
+import pytest
+
+from oracle import pymodel as pm
+from tests import vectors as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import dusk_zerocaf_amd as z
+    e = z.Engine()
+    yield e
+    e.close()
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+# ------------------------------------------------------------------ reference KATs through the C ABI
+def test_kat_field(eng, kats):
+    f = lambda n: np.array([kats["field"][n]["limbs"]], dtype=np.uint64)
+    A, B, Cc = f("A"), f("B"), f("C")
+    assert eq(eng.fe_add(A, B), f("A_PLUS_B"))                  # addition_without_modulo
+    assert eq(eng.fe_sub(A, B), f("A_MINUS_B"))                 # subtraction_with_mod
+    assert eq(eng.fe_sub(B, A), f("B_MINUS_A"))
+    assert eq(eng.fe_mul(A, B), f("A_TIMES_B"))                 # mul_with_modulo
+    assert eq(eng.fe_mul(A, Cc), f("A_TIMES_C"))
+    assert eq(eng.fe_square(A), f("A_SQUARE"))
+    assert eq(eng.fe_square(B), f("B_SQUARE"))
+    assert eq(eng.fe_neg(A), f("MINUS_A")) and eq(eng.fe_neg(B), f("MINUS_B"))
+    for n in "ABC":                                             # savas_koc_inverse
+        out, ok = eng.fe_invert(f(n))
+        assert ok[0] == 1 and eq(out, f("INV_MOD_" + n))
+    out, ok = eng.fe_invert(np.zeros((1, 5), dtype=np.uint64))
+    assert ok[0] == 0 and not out.any()
+    mb = np.array([kats["field_bytes"]["MINUS_ONE_BYTES"]["bytes"]], dtype=np.uint8)
+    m1 = np.array([[671914833335276, 3916664325105025, 1367801, 0, 17592186044416]], dtype=np.uint64)
+    assert eq(eng.fe_from_bytes(mb), m1) and eq(eng.fe_to_bytes(m1), mb)
+    one = np.array([[1, 0, 0, 0, 0]], dtype=np.uint64)
+    r, sq = eng.fe_sqrt_ratio_i(one, np.array([[27, 0, 0, 0, 0]], dtype=np.uint64))   # inv_sqrt
+    assert eq(eng.fe_neg(r), f("INV_SQRT_27"))
+
+
+def test_kat_scalar(eng, kats):
+    s = lambda n: np.array([kats["scalar"][n]["limbs"]], dtype=np.uint64)
+    assert eq(eng.sc_sub(s("A"), s("B")), s("AB")) and eq(eng.sc_sub(s("B"), s("A")), s("BA"))
+    assert eq(eng.sc_add(s("BA"), s("A")), s("B"))
+    assert not eng.sc_add(s("AB"), s("BA")).any()
+    assert eq(eng.sc_mul(s("X"), s("Y")), s("X_TIMES_Y"))       # scalar_mul (X = 2^250-1 > L)
+    assert eq(eng.sc_square(s("Y")), s("Y_SQ"))
+    okb = np.frombuffer((pm.L - 1).to_bytes(32, "little") + pm.L.to_bytes(32, "little"), dtype=np.uint8).reshape(2, 32)
+    out, ok = eng.sc_from_bytes(okb)
+    assert ok.tolist() == [1, 0] and eq(eng.sc_to_bytes(out[:1]), okb[:1])
+
+
+def test_kat_edwards_and_ristretto(eng, kats):
+    def ept(name):
+        c = kats["edwards_points"][name]["coords"]
+        return np.array([c["X"] + c["Y"] + c["Z"] + c["T"]], dtype=np.uint64)
+    p1, p2 = ept("P1_EXTENDED"), ept("P2_EXTENDED")
+    assert eq(eng.ed_add(p1, p2), ept("P4_EXTENDED"))           # extended_point_addition: limb-exact
+    assert eng.ed_eq(eng.ed_double(p1), ept("P3_EXTENDED"))[0] == 1
+    d3 = eng.ed_double(eng.ed_double(eng.ed_double(p1)))
+    assert eng.ed_eq(eng.ed_mul_by_cofactor(p1), d3)[0] == 1    # extended_double_and_add
+    for n in ("P1", "P2"):                                      # point_compression / decompression
+        comp = np.array([kats["edwards_compressed"][n + "_COMPRESSED"]["bytes"]], dtype=np.uint8)
+        out, ok = eng.ed_compress(ept(n + "_EXTENDED"))
+        assert ok[0] == 1 and eq(out, comp)
+        dec, ok = eng.ed_decompress(comp)
+        assert ok[0] == 1 and eq(dec, ept(n + "_EXTENDED"))
+    fail = np.array([kats["edwards_inline_bytes"][2]["bytes"]], dtype=np.uint8)
+    assert eng.ed_decompress(fail)[1][0] == 0
+    bp = kats["constants_points"]["BASEPOINT"]["coords"]
+    B = np.array([bp["X"] + bp["Y"] + bp["Z"] + bp["T"]], dtype=np.uint64)
+    Lk = np.array([kats["constants"]["L"]["limbs"]], dtype=np.uint64)
+    ident = np.array([V.IDENT_ROW], dtype=np.uint64)
+    assert eng.ed_eq(eng.ed_scalar_mul(B, Lk), ident)[0] == 1   # unique_basepoint_test: B*L == identity
+    enc = [bytes.fromhex(x["hex"]) for x in kats["ristretto_small_multiples"]]
+    P = ident.copy()
+    for i in range(16):                                         # valid_encoding_test_vectors
+        assert bytes(eng.ris_compress(P)[0].tolist()) == enc[i], i
+        P = eng.ed_add(P, B)
+    arr = np.frombuffer(b"".join(enc), dtype=np.uint8).reshape(16, 32)
+    pts, ok = eng.ris_decompress(arr)
+    assert ok.all() and eq(eng.ris_compress(pts), arr)
+    assert eng.ris_eq(pts[1:2], B)[0] == 1                      # basepoint_compr_decompr
+    four = eng.ed_mul_by_pow_2(eng.ed_sub(B, pts[1:2]), 2)      # four_torsion_diff
+    out, okc = eng.ed_compress(four)
+    assert okc[0] == 1 and out[0].tolist() == [1] + [0] * 31
+    with pytest.raises(Exception):
+        eng.ed_mul_by_pow_2(B, 250)                             # Scalar::two_pow_k asserts k < 250
+
+
+# ------------------------------------------------------------------ bulk parity vs the oracle
+@pytest.mark.parametrize("n", [1, 255, 257, 1 << 16])
+def test_fe_and_scalar_ops_bulk(eng, oracle, n):
+    for mod, edge, ops in ((pm.P, V.FE_EDGE, ("fe_add", "fe_sub", "fe_mul", "fe_neg", "fe_square")),
+                           (pm.L, V.SC_EDGE, ("sc_add", "sc_sub", "sc_mul", "sc_neg", "sc_square"))):
+        a = V.rand_fe_np(n, V.SEED + 10 + n, mod)
+        b = V.rand_fe_np(n, V.SEED + 11 + n, mod)
+        k = min(n, len(edge))
+        a[:k] = V.limbs_array(edge[:k])
+        b[:k] = V.limbs_array(list(reversed(edge))[:k])
+        for name in ops:
+            if name.endswith(("neg", "square")):
+                assert eq(getattr(eng, name)(a), getattr(oracle, name)(a)), name
+            else:
+                assert eq(getattr(eng, name)(a, b), getattr(oracle, name)(a, b)), name
+
+
+def test_fe_mul_full_size_2_20(eng, oracle):
+    n = 1 << 20                                                  # BASELINE config 2
+    a, b = V.rand_fe_np(n, V.SEED + 20), V.rand_fe_np(n, V.SEED + 21)
+    assert eq(eng.fe_mul(a, b), oracle.fe_mul(a, b))
+    assert eq(eng.fe_square(a), oracle.fe_square(a))
+
+
+def test_fe_invert_bulk(eng, oracle):
+    n = (1 << 14) + 3
+    a = V.rand_fe_np(n, V.SEED + 22)
+    a[5] = 0
+    a[n - 1] = 0
+    out, ok = eng.fe_invert(a)
+    want, wok = oracle.fe_invert(a)
+    assert eq(ok, wok) and eq(out, want) and ok.sum() == n - 2
+    # full size: a * a^-1 == 1 for every element (size-independent property)
+    big = V.rand_fe_np(1 << 20, V.SEED + 23)
+    inv, ok = eng.fe_invert(big)
+    prod = eng.fe_mul(big, inv)
+    assert ok.all() and (prod[:, 0] == 1).all() and not prod[:, 1:].any()
+
+
+def test_sqrt_ratio_bulk(eng, oracle):
+    n = 1500
+    u, v = V.rand_fe_np(n, V.SEED + 24), V.rand_fe_np(n, V.SEED + 25)
+    u[0] = 0
+    v[1] = 0
+    u[2] = 0
+    v[2] = 0
+    out, sq = eng.fe_sqrt_ratio_i(u, v)
+    want, wsq = oracle.fe_sqrt_ratio_i(u, v)
+    assert eq(sq, wsq) and eq(out, want) and 0 < sq.sum() < n
+
+
+def test_bytes_codecs_bulk(eng, oracle):
+    rng = np.random.default_rng(V.SEED + 26)
+    raw = rng.integers(0, 256, size=(5000, 32), dtype=np.uint8)
+    assert eq(eng.fe_from_bytes(raw), oracle.fe_from_bytes(raw))
+    out, ok = eng.sc_from_bytes(raw)
+    wout, wok = oracle.sc_from_bytes(raw)
+    assert eq(out, wout) and eq(ok, wok)
+    a = V.rand_fe_np(5000, V.SEED + 27)
+    assert eq(eng.fe_to_bytes(a), oracle.fe_to_bytes(a))
+
+
+@pytest.mark.parametrize("n", [1, 63, 300])
+def test_point_ops_bulk(eng, oracle, n):
+    P = V.base_multiples(oracle, n, V.SEED + 30 + n)
+    Q = V.base_multiples(oracle, n, V.SEED + 31 + n)
+    P[0] = V.IDENT_ROW
+    if n > 2:
+        Q[1] = V.IDENT_ROW
+        Q[2] = P[2]
+    assert eq(eng.ed_add(P, Q), oracle.ed_add(P, Q))
+    assert eq(eng.ed_sub(P, Q), oracle.ed_sub(P, Q))
+    assert eq(eng.ed_double(P), oracle.ed_double(P))
+    assert eq(eng.ed_neg(P), oracle.ed_neg(P))
+    xy, ok = eng.ed_to_affine(P)
+    wxy, wok = oracle.ed_to_affine(P)
+    assert eq(ok, wok) and eq(xy, wxy)
+    assert eq(eng.ed_eq(P, Q), oracle.ed_eq(P, Q))
+    assert eq(eng.ris_eq(P, Q), oracle.ris_eq(P, Q))
+    assert eq(eng.ed_mul_by_pow_2(P, 5), oracle.ed_mul_by_pow_2(P, 5))
+
+
+def _edge_scalars(K):
+    K[0] = 0
+    if len(K) > 8:
+        K[1] = [1, 0, 0, 0, 0]
+        K[2] = pm.limbs(pm.L)
+        K[3] = pm.limbs(2**249 - 1)
+        K[4] = [(1 << 52) - 1] * 5                               # all 260 bits of a raw limb pattern
+        K[5] = [0, 0, 0, 0, 1 << 47]
+        K[6] = pm.limbs(8)
+        K[7] = pm.limbs(pm.L - 1)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 252), (65, 249), (1000, 252), (4096 + 77, 252)])
+def test_scalar_mul_strict_limbs(eng, oracle, n, bits):
+    """config 3 at oracle-sized batches: (X:Y:Z:T) limbs identical to double_and_add."""
+    P = V.base_multiples(oracle, n, V.SEED + 40 + n)
+    K = V.rand_scalars_np(n, V.SEED + 41 + n, bits=bits)
+    _edge_scalars(K)
+    if n > 10:
+        P[9] = V.IDENT_ROW
+    assert eq(eng.ed_scalar_mul(P, K), oracle.ed_scalar_mul(P, K))
+
+
+def test_scalar_mul_full_size_properties(eng, oracle):
+    """config 3 at 2^20: linearity (k1+k2)P == k1P + k2P on every element, plus an
+    oracle-checked stride sample of exact limbs."""
+    n = 1 << 20
+    small = V.base_multiples(oracle, 1 << 10, V.SEED + 50)
+    P = np.tile(small, (n >> 10, 1))
+    k1 = V.rand_scalars_np(n, V.SEED + 51, bits=248)
+    k2 = V.rand_scalars_np(n, V.SEED + 52, bits=248)
+    ks = oracle.sc_add(np.zeros_like(k1), k1)                     # k1 < 2^248 < L: unchanged
+    assert eq(ks, k1)
+    ksum = k1.copy()                                              # plain integer sum < 2^249
+    carry = np.zeros(n, dtype=np.uint64)
+    for j in range(5):
+        t = k1[:, j] + k2[:, j] + carry
+        ksum[:, j] = t & np.uint64((1 << 52) - 1)
+        carry = t >> np.uint64(52)
+    r1, r2, rs = eng.ed_scalar_mul(P, k1), eng.ed_scalar_mul(P, k2), eng.ed_scalar_mul(P, ksum)
+    assert eng.ed_eq(eng.ed_add(r1, r2), rs).all()
+    idx = np.arange(0, n, 4099)
+    assert eq(rs[idx], oracle.ed_scalar_mul(P[idx], ksum[idx]))
+
+
+def test_codecs_bulk(eng, oracle):
+    n = 700
+    P = V.base_multiples(oracle, n, V.SEED + 60)
+    P[0] = V.IDENT_ROW
+    enc, ok = eng.ed_compress(P)
+    wenc, wok = oracle.ed_compress(P)
+    assert eq(ok, wok) and eq(enc, wenc)
+    dec, ok = eng.ed_decompress(wenc)
+    wdec, wok = oracle.ed_decompress(wenc)
+    assert eq(ok, wok) and eq(dec, wdec)
+    renc = eng.ris_compress(P)
+    wrenc = oracle.ris_compress(P)
+    assert eq(renc, wrenc)
+    rdec, ok = eng.ris_decompress(wrenc)
+    wrdec, wok = oracle.ris_decompress(wrenc)
+    assert eq(ok, wok) and eq(rdec, wrdec) and ok.all()
+    rng = np.random.default_rng(V.SEED + 61)
+    raw = rng.integers(0, 256, size=(3000, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x0F
+    raw[:5, 31] = 0xFF
+    rdec, ok = eng.ris_decompress(raw)
+    wrdec, wok = oracle.ris_decompress(raw)
+    assert eq(ok, wok) and eq(rdec, wrdec) and 0 < ok.sum() < 3000
+    raw[:5, 31] = 0x8F
+    dec, ok = eng.ed_decompress(raw)
+    wdec, wok = oracle.ed_decompress(raw)
+    assert eq(ok, wok) and eq(dec, wdec) and 0 < ok.sum() < 3000
+    # invalid Edwards points (not on the curve) hit the reference's unwrap panics -> ok = 0 on both sides
+    bad = P[:64].copy()
+    bad[:, 5] ^= np.uint64(1)
+    enc, ok = eng.ed_compress(bad)
+    wenc, wok = oracle.ed_compress(bad)
+    assert eq(ok, wok) and eq(enc, wenc)
+
+
+def test_ristretto_roundtrip_mul(eng, oracle):
+    """config 4 shape: decompress -> scalar-mul -> compress, with ~1% invalid encodings."""
+    n = 2048 + 5
+    P = V.base_multiples(oracle, n, V.SEED + 70)
+    enc = oracle.ris_compress(P)
+    rng = np.random.default_rng(V.SEED + 71)
+    bad = rng.choice(n, size=n // 100, replace=False)
+    enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
+    K = V.rand_scalars_np(n, V.SEED + 72, bits=252)
+    _edge_scalars(K)
+    out, ok = eng.ris_roundtrip_mul(enc, K)
+    wout, wok = oracle.ris_roundtrip_mul(enc, K)
+    assert eq(ok, wok) and eq(out, wout) and 0 < (ok == 0).sum() <= len(bad)
+
+
+def test_msm_small(eng, oracle):
+    for n in (1, 2, 3, 64, 257):
+        P = V.base_multiples(oracle, n, V.SEED + 80 + n)
+        K = V.rand_scalars_np(n, V.SEED + 81 + n, bits=249)
+        got = eng.msm(P, K)
+        want = oracle.msm_naive(P, K)
+        assert oracle.ed_eq(got, want)[0] == 1
+        assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
+
+
+def test_device_resident_buffers(eng, oracle):
+    """Same results when the caller hands over HBM-resident buffers (torch tensors) and a
+    borrowed stream: the zero-copy path the bench uses."""
+    import torch
+    n = 3000
+    P = V.base_multiples(oracle, n, V.SEED + 90)
+    K = V.rand_scalars_np(n, V.SEED + 91, bits=252)
+    dP = torch.from_numpy(P.view(np.int64)).cuda()
+    dK = torch.from_numpy(K.view(np.int64)).cuda()
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        out = eng.ed_scalar_mul(dP, dK)
+        torch.cuda.synchronize()
+        assert eq(out.cpu().numpy().view(np.uint64), oracle.ed_scalar_mul(P, K))
+        a, b = V.rand_fe_np(n, V.SEED + 92), V.rand_fe_np(n, V.SEED + 93)
+        da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        prod = eng.fe_mul(da, db)
+        torch.cuda.synchronize()
+        assert eq(prod.cpu().numpy().view(np.uint64), oracle.fe_mul(a, b))
+        with pytest.raises(Exception):
+            eng.fe_mul(da, b)                                     # host/device mix is refused
+    finally:
+        eng.set_stream(0)

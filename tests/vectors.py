@@ -1,0 +1,60 @@
+"""Seeded synthetic inputs shared by the CPU-tier and GPU-tier parity tests
+(same bytes for the oracle and for the HIP path)."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from oracle import pymodel as pm
+
+SEED = 0x5EED0000
+
+FE_EDGE = [0, 1, 2, pm.P - 1, pm.P - 2, (pm.P - 1) // 2, (pm.P + 1) // 2, 2**52, 2**104, 2**156, 2**208,
+           2**252, 2**52 - 1, 2**29 - 1, 2**29, 2**232, 2**252 + 1,
+           182687704666362864775460604089535377456991567872,  # field.rs KAT A
+           904625697166532776746648320197686575422163851717637391703244652875051672039,  # KAT B
+           2009874587549]  # KAT C
+SC_EDGE = [0, 1, 2, pm.L - 1, pm.L - 2, (pm.L - 1) // 2, 2**52, 2**104, 2**156, 2**208, 2**249, 2**249 - 1]
+
+
+def limbs_array(vals):
+    return np.array([pm.limbs(v) for v in vals], dtype=np.uint64)
+
+
+def rand_fe(n, seed, modulus=pm.P, edge=FE_EDGE):
+    rng = random.Random(seed)
+    vals = [rng.randrange(modulus) for _ in range(n)]
+    k = min(len(edge), n)
+    vals[:k] = edge[:k]
+    return vals
+
+
+def rand_fe_np(n, seed, modulus=pm.P):
+    """Vectorised uniform-ish canonical elements for big batches (rejection on the top limb)."""
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)
+    top = modulus >> 208
+    out[:, 4] = rng.integers(0, top, size=n, dtype=np.uint64)   # < top limb of modulus => value < modulus
+    return out
+
+
+def rand_scalars_np(n, seed, bits=252):
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)
+    out[:, 4] = rng.integers(0, 1 << (bits - 208), size=n, dtype=np.uint64)
+    return out
+
+
+def base_multiples(oracle, n, seed):
+    """n valid subgroup points in non-trivial extended coordinates: r_i * B via the oracle."""
+    k = rand_scalars_np(n, seed, bits=249)
+    b = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (n, 1))
+    return oracle.ed_scalar_mul(b, k)
+
+
+def pts_np(pts):
+    return np.array([sum(pm.pt_limbs(p), []) for p in pts], dtype=np.uint64)
+
+
+IDENT_ROW = [0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]
