@@ -67,12 +67,34 @@ def make_inputs(eng, torch, n, seed, workload):
     return d
 
 
+def usable_cores():
+    """Threads this process may really run at once: affinity mask capped by the cgroup quota."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    c = min(c, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    c = min(c, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, c)
+
+
 def cpu_baseline(workload, sample, host_inputs):
     """Oracle (reference-shaped C restatement) on the host cores, bounded sample."""
     from oracle import zc_ref
     zc_ref.build()
     zc_ref.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     chunks = np.array_split(np.arange(sample), cores)
     if workload == "fe_mul":
         a, b = host_inputs
@@ -198,7 +220,7 @@ def main():
     cpu = None
     sample = args.cpu_sample
     if sample < 0:
-        sample = {"scalar_mul": 1 << 13, "ristretto": 1 << 13, "fe_mul": 1 << 22}[args.workload] * max(1, (os.cpu_count() or 1) // 8)
+        sample = {"scalar_mul": 1 << 11, "ristretto": 1 << 11, "fe_mul": 1 << 20}[args.workload] * usable_cores()
     if sample:
         if args.workload == "fe_mul":
             a, b = data["host"]

@@ -62,6 +62,28 @@ class ZerocafHipError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, the one our library needs); if our library
+    pulled in /opt/rocm's copy first, a later `import torch` would bring a second runtime
+    that sees no GPU.  So when torch is installed, map its copy before ours."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load() -> C.CDLL:
     """Load the HIP library.  Fails loudly when it has not been built."""
     global _lib
@@ -71,11 +93,12 @@ def load() -> C.CDLL:
         raise ZerocafHipError(
             "libzerocaf_hip.so is missing (%s): build it with `python -m dusk_zerocaf_amd.build`; "
             "there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     lib.zc_ctx_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_ctx)]
     lib.zc_ctx_create.restype = C.c_int
     lib.zc_ctx_destroy.argtypes = [_ctx]
-    lib.zc_ctx_set_stream.argtypes = [_ctx, C.c_void_p]
+    lib.zc_ctx_set_stream.argtypes = [_ctx, C.c_void_p, C.c_int]
     lib.zc_ctx_synchronize.argtypes = [_ctx]
     lib.zc_device_count.restype = C.c_int
     lib.zc_last_error.restype = C.c_char_p

@@ -41,11 +41,12 @@ struct DevState {
     int device = 0;
     hipStream_t stream = nullptr;       // owned
     hipStream_t borrowed = nullptr;     // set by zc_ctx_set_stream (device 0 only)
+    bool use_borrowed = false;
     void* scratch[MAX_ARGS] = {};
     size_t scratch_bytes[MAX_ARGS] = {};
     void* tmp[2] = {};                  // zc_msm partials
     size_t tmp_bytes[2] = {};
-    hipStream_t s() const { return borrowed ? borrowed : stream; }
+    hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
 }  // namespace
@@ -281,11 +282,12 @@ int zc_ctx_destroy(zc_ctx* ctx)
     return ZC_OK;
 }
 
-int zc_ctx_set_stream(zc_ctx* ctx, void* hip_stream)
+int zc_ctx_set_stream(zc_ctx* ctx, void* hip_stream, int external)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->devs[0].borrowed = (hipStream_t)hip_stream;
+    ctx->devs[0].borrowed = external ? (hipStream_t)hip_stream : nullptr;
+    ctx->devs[0].use_borrowed = external != 0;
     return ZC_OK;
 }
 

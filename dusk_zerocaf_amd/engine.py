@@ -47,7 +47,12 @@ class Engine:
             pass
 
     def set_stream(self, stream_handle):
-        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(stream_handle)), "zc_ctx_set_stream")
+        """Launch on the caller's HIP stream (handle 0 = the HIP null stream, which is what
+        torch.cuda.current_stream().cuda_stream is by default)."""
+        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(stream_handle), 1), "zc_ctx_set_stream")
+
+    def use_own_stream(self):
+        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, None, 0), "zc_ctx_set_stream")
 
     def synchronize(self):
         _lib.check(self.lib.zc_ctx_synchronize(self.ctx), "zc_ctx_synchronize")

@@ -60,9 +60,10 @@ typedef enum zc_status {
  * elements, no exchange step).                                                  */
 int zc_ctx_create(const int *devices, int ndev, zc_ctx **out);
 int zc_ctx_destroy(zc_ctx *ctx);
-/* Borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for
- * device 0 of the context; NULL restores the context's own stream.             */
-int zc_ctx_set_stream(zc_ctx *ctx, void *hip_stream);
+/* external != 0: launch on the caller's hipStream_t `hip_stream` (e.g.
+ * torch.cuda.current_stream().cuda_stream; NULL there means the HIP null stream) for
+ * device 0 of the context.  external == 0: go back to the context's own stream.   */
+int zc_ctx_set_stream(zc_ctx *ctx, void *hip_stream, int external);
 int zc_ctx_synchronize(zc_ctx *ctx);
 int zc_device_count(void);
 const char *zc_last_error(void);

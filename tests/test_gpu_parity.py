@@ -306,4 +306,4 @@ def test_device_resident_buffers(eng, oracle):
         with pytest.raises(Exception):
             eng.fe_mul(da, b)                                     # host/device mix is refused
     finally:
-        eng.set_stream(0)
+        eng.use_own_stream()
