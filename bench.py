@@ -30,8 +30,6 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_UNIT = {"scalar_mul": 360, "fe_mul": 120, "ristretto": 104}   # SURVEY 8(d) algorithmic bytes
 # measured on MI355X with tools/ubench (profiles/r01_ubench.txt): independent v_mad_u64_u32
 # chains, all CUs -- wave-instructions x 64 lanes per second
-MAD_PEAK_PER_S = None            # filled from profiles/r01_ubench.json when present
-MADS_PER_POINT_ADD = 10 * (126 + 9)   # 10 Montgomery muls x (81+45 v_mad_u64_u32 + 9 v_mul_lo_u32)
 
 
 def log(*a):
@@ -188,19 +186,35 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "kernel": {"scalar_mul": "k_ed_scalar_mul", "fe_mul": "k_fe_mul", "ristretto": "k_ris_roundtrip_mul"}[args.workload],
                 "kernel_avg_ms": round(kern_avg_s * 1e3, 4), "algorithmic_bytes_per_unit": unit_bytes}
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE, profiles/r01_pmc_summary.md), scaled to this launch's unit count
     pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if os.path.exists(pmc):
         try:
-            roofline["traffic"] = json.load(open(pmc)).get(args.workload)
+            t = json.load(open(pmc))
+            if args.workload == "scalar_mul":
+                roofline["traffic"] = round(t["scalar_mul"] * n / (1 << 20))
+            elif args.workload == "fe_mul":
+                roofline["traffic"] = round(t["fe_mul_per_unit_bytes"] * n)
         except Exception:
             pass
     ub = os.path.join(ROOT, "profiles", "r01_ubench.json")
     if args.workload != "fe_mul" and os.path.exists(ub):
         try:
-            peak = float(json.load(open(ub))["v_mad_u64_u32_lane_ops_per_s"])
-            # wave steps per point: measured by the kernel design (max over lanes of bitlen-1+popcount ~ 395)
-            roofline["valu"] = {"note": "scalar-mul is integer-VALU bound, not HBM bound",
-                                "mad_peak_per_s": peak}
+            u = json.load(open(ub))
+            mad_peak = float(u["v_mad_u64_u32_lane_ops_per_s"])
+            alu_peak = float(u["v_add_u32_lane_ops_per_s"])
+            insts = float(json.load(open(pmc))["scalar_mul_valu_insts_per_launch"]) * n / (1 << 20)
+            # instruction mix of one unified step (ISA histogram of k_ed_scalar_mul): 10 x (126
+            # v_mad_u64_u32 + 9 v_mul_lo_u32 + 52 64-bit shift/add) at the mad rate, rest 32-bit ALU
+            heavy = 10 * (126 + 9 + 52) / 2450.0
+            t_min = insts * 64 * (heavy / mad_peak + (1 - heavy) / alu_peak)
+            roofline["valu"] = {
+                "note": "this kernel is integer-VALU issue bound, not HBM bound (0.2% of HBM peak is expected)",
+                "valu_wave_insts_per_launch": insts, "mad_class_fraction": round(heavy, 3),
+                "v_mad_u64_u32_peak_lane_ops_per_s": mad_peak, "alu32_peak_lane_ops_per_s": alu_peak,
+                "issue_bound_ms": round(t_min * 1e3, 3),
+                "frac_of_issue_bound": round(t_min / kern_avg_s, 4) if args.workload == "scalar_mul" else None}
         except Exception:
             pass
 
@@ -220,7 +234,7 @@ def main():
     cpu = None
     sample = args.cpu_sample
     if sample < 0:
-        sample = {"scalar_mul": 1 << 11, "ristretto": 1 << 11, "fe_mul": 1 << 20}[args.workload] * usable_cores()
+        sample = {"scalar_mul": 1 << 13, "ristretto": 1 << 13, "fe_mul": 1 << 24}[args.workload] * usable_cores()
     if sample:
         if args.workload == "fe_mul":
             a, b = data["host"]
