@@ -1,0 +1,351 @@
+// zerocaf.hpp -- C++ host-side mirror of zerocaf's operator surface for the hot path,
+// over the C ABI of libzerocaf_hip.so (include/zerocaf_hip.h).  Same names, argument
+// meaning and error behaviour as the reference's Rust API:
+//   FieldElement   src/backend/u64/field.rs  (Add/Sub/Neg/Mul :170-275, Square :302-315,
+//                  inverse :854-925 (throws where Rust panics), from_bytes/to_bytes :563-631,
+//                  sqrt_ratio_i :462-503, inv_sqrt :443-460)
+//   Scalar         src/backend/u64/scalar.rs (Add/Sub/Neg/Mul :139-270, Square :272-283,
+//                  from_bytes :445-467 (throws on > L-1), to_bytes :477-516, two_pow_k :525-552)
+//   EdwardsPoint   src/edwards.rs (identity :381-391, Neg :440-463, Add :465-501, Sub :503-545,
+//                  Mul<Scalar> :547-577, Double :579-592, compress :613-629, == :360-370)
+//   CompressedEdwardsY::decompress :313-326 (std::optional = Option)
+//   RistrettoPoint / CompressedRistretto  src/ristretto.rs (:96-154, :166-176, :224-425)
+//   mul_by_cofactor / mul_by_pow_2  src/edwards.rs:174-191
+// Single-element operators are batches of one (convenience / tests); use the *_batch
+// functions for throughput.  All arithmetic runs on the GPU; there is no CPU path.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/zerocaf_hip.h"
+
+namespace zerocaf {
+
+class Backend {
+public:
+    static zc_ctx* ctx()
+    {
+        static Backend b;
+        return b.ctx_;
+    }
+    static void check(int rc, const char* what)
+    {
+        if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + zc_last_error());
+    }
+
+private:
+    Backend() { check(zc_ctx_create(nullptr, 0, &ctx_), "zc_ctx_create"); }
+    ~Backend() { zc_ctx_destroy(ctx_); }
+    zc_ctx* ctx_ = nullptr;
+};
+
+struct Scalar;
+
+struct FieldElement {
+    std::array<uint64_t, 5> l{};
+    FieldElement() = default;
+    FieldElement(std::array<uint64_t, 5> v) : l(v) {}
+    explicit FieldElement(uint64_t v) { l = {v & ((1ull << 52) - 1), v >> 52, 0, 0, 0}; }   // From<u64>, field.rs:124-133
+    static FieldElement zero() { return FieldElement(); }
+    static FieldElement one() { return FieldElement(std::array<uint64_t, 5>{1, 0, 0, 0, 0}); }
+    static FieldElement minus_one() { return FieldElement(std::array<uint64_t, 5>{671914833335276ull, 3916664325105025ull, 1367801ull, 0, 17592186044416ull}); }
+
+    FieldElement operator+(const FieldElement& b) const { FieldElement r; Backend::check(zc_fe_add(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_fe_add"); return r; }
+    FieldElement operator-(const FieldElement& b) const { FieldElement r; Backend::check(zc_fe_sub(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_fe_sub"); return r; }
+    FieldElement operator*(const FieldElement& b) const { FieldElement r; Backend::check(zc_fe_mul(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_fe_mul"); return r; }
+    FieldElement operator-() const { FieldElement r; Backend::check(zc_fe_neg(Backend::ctx(), l.data(), r.l.data(), 1), "zc_fe_neg"); return r; }
+    FieldElement square() const { FieldElement r; Backend::check(zc_fe_square(Backend::ctx(), l.data(), r.l.data(), 1), "zc_fe_square"); return r; }
+    FieldElement inverse() const
+    {
+        FieldElement r;
+        uint8_t ok = 0;
+        Backend::check(zc_fe_invert(Backend::ctx(), l.data(), r.l.data(), &ok, 1), "zc_fe_invert");
+        if (!ok) throw std::domain_error("inverse of zero");             // field.rs:864 assert!
+        return r;
+    }
+    FieldElement operator/(const FieldElement& b) const
+    {
+        if (b == zero()) throw std::domain_error("Cannot divide by zero.");   // field.rs:285
+        return *this * b.inverse();
+    }
+    // (Choice, FieldElement), field.rs:462-503
+    std::pair<bool, FieldElement> sqrt_ratio_i(const FieldElement& v) const
+    {
+        FieldElement r;
+        uint8_t sq = 0;
+        Backend::check(zc_fe_sqrt_ratio_i(Backend::ctx(), l.data(), v.l.data(), r.l.data(), &sq, 1), "zc_fe_sqrt_ratio_i");
+        return {sq != 0, r};
+    }
+    std::pair<bool, FieldElement> inv_sqrt() const { return one().sqrt_ratio_i(*this); }
+    static FieldElement from_bytes(const std::array<uint8_t, 32>& b)
+    {
+        FieldElement r;
+        Backend::check(zc_fe_from_bytes(Backend::ctx(), b.data(), r.l.data(), 1), "zc_fe_from_bytes");
+        return r;
+    }
+    std::array<uint8_t, 32> to_bytes() const
+    {
+        std::array<uint8_t, 32> b{};
+        Backend::check(zc_fe_to_bytes(Backend::ctx(), l.data(), b.data(), 1), "zc_fe_to_bytes");
+        return b;
+    }
+    bool operator==(const FieldElement& o) const { return to_bytes() == o.to_bytes(); }     // src/field.rs:93-106
+    bool operator!=(const FieldElement& o) const { return !(*this == o); }
+    uint64_t operator[](size_t i) const { return l[i]; }
+};
+
+struct Scalar {
+    std::array<uint64_t, 5> l{};
+    Scalar() = default;
+    Scalar(std::array<uint64_t, 5> v) : l(v) {}
+    explicit Scalar(uint64_t v) { l = {v & ((1ull << 52) - 1), v >> 52, 0, 0, 0}; }
+    static Scalar zero() { return Scalar(); }
+    static Scalar one() { return Scalar(std::array<uint64_t, 5>{1, 0, 0, 0, 0}); }
+    static Scalar minus_one() { return Scalar(std::array<uint64_t, 5>{1129677152307298ull, 1363544697812651ull, 714439ull, 0, 2199023255552ull}); }
+    static Scalar two_pow_k(uint64_t k)                                     // scalar.rs:525-552
+    {
+        if (k >= 250) throw std::domain_error("Exponent can't be greater than the sub-group order");
+        Scalar s;
+        s.l[k / 52] = 1ull << (k % 52);
+        return s;
+    }
+    Scalar operator+(const Scalar& b) const { Scalar r; Backend::check(zc_sc_add(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_sc_add"); return r; }
+    Scalar operator-(const Scalar& b) const { Scalar r; Backend::check(zc_sc_sub(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_sc_sub"); return r; }
+    Scalar operator*(const Scalar& b) const { Scalar r; Backend::check(zc_sc_mul(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_sc_mul"); return r; }
+    Scalar operator-() const { Scalar r; Backend::check(zc_sc_neg(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_neg"); return r; }
+    Scalar square() const { Scalar r; Backend::check(zc_sc_square(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_square"); return r; }
+    bool is_even() const { return (l[0] & 1) == 0; }                         // scalar.rs:346-348
+    static Scalar from_bytes(const std::array<uint8_t, 32>& b)
+    {
+        Scalar r;
+        uint8_t ok = 0;
+        Backend::check(zc_sc_from_bytes(Backend::ctx(), b.data(), r.l.data(), &ok, 1), "zc_sc_from_bytes");
+        if (!ok) throw std::domain_error("scalar bytes > L - 1");            // scalar.rs:465 assert!
+        return r;
+    }
+    std::array<uint8_t, 32> to_bytes() const
+    {
+        std::array<uint8_t, 32> b{};
+        Backend::check(zc_sc_to_bytes(Backend::ctx(), l.data(), b.data(), 1), "zc_sc_to_bytes");
+        return b;
+    }
+    bool operator==(const Scalar& o) const { return to_bytes() == o.to_bytes(); }           // src/scalar.rs:78-91
+    uint64_t operator[](size_t i) const { return l[i]; }
+};
+
+struct CompressedEdwardsY;
+struct CompressedRistretto;
+
+struct EdwardsPoint {
+    FieldElement X, Y, Z, T;
+    static EdwardsPoint identity() { return {FieldElement::zero(), FieldElement::one(), FieldElement::one(), FieldElement::zero()}; }
+    void flat(uint64_t* o) const
+    {
+        std::memcpy(o, X.l.data(), 40);
+        std::memcpy(o + 5, Y.l.data(), 40);
+        std::memcpy(o + 10, Z.l.data(), 40);
+        std::memcpy(o + 15, T.l.data(), 40);
+    }
+    static EdwardsPoint unflat(const uint64_t* p)
+    {
+        EdwardsPoint r;
+        std::memcpy(r.X.l.data(), p, 40);
+        std::memcpy(r.Y.l.data(), p + 5, 40);
+        std::memcpy(r.Z.l.data(), p + 10, 40);
+        std::memcpy(r.T.l.data(), p + 15, 40);
+        return r;
+    }
+    EdwardsPoint operator+(const EdwardsPoint& q) const
+    {
+        uint64_t a[20], b[20], o[20];
+        flat(a); q.flat(b);
+        Backend::check(zc_ed_add(Backend::ctx(), a, b, o, 1), "zc_ed_add");
+        return unflat(o);
+    }
+    EdwardsPoint operator-(const EdwardsPoint& q) const
+    {
+        uint64_t a[20], b[20], o[20];
+        flat(a); q.flat(b);
+        Backend::check(zc_ed_sub(Backend::ctx(), a, b, o, 1), "zc_ed_sub");
+        return unflat(o);
+    }
+    EdwardsPoint operator-() const
+    {
+        uint64_t a[20], o[20];
+        flat(a);
+        Backend::check(zc_ed_neg(Backend::ctx(), a, o, 1), "zc_ed_neg");
+        return unflat(o);
+    }
+    EdwardsPoint double_() const
+    {
+        uint64_t a[20], o[20];
+        flat(a);
+        Backend::check(zc_ed_double(Backend::ctx(), a, o, 1), "zc_ed_double");
+        return unflat(o);
+    }
+    EdwardsPoint operator*(const Scalar& k) const                           // double_and_add, edwards.rs:102-120
+    {
+        uint64_t a[20], o[20];
+        flat(a);
+        Backend::check(zc_ed_scalar_mul(Backend::ctx(), a, k.l.data(), o, 1, ZC_SCALAR_MUL_STRICT), "zc_ed_scalar_mul");
+        return unflat(o);
+    }
+    bool operator==(const EdwardsPoint& q) const                            // affine equality, edwards.rs:360-370
+    {
+        uint64_t a[20], b[20];
+        uint8_t e = 0;
+        flat(a); q.flat(b);
+        Backend::check(zc_ed_eq(Backend::ctx(), a, b, &e, 1), "zc_ed_eq");
+        return e != 0;
+    }
+    inline CompressedEdwardsY compress() const;
+};
+
+struct CompressedEdwardsY {
+    std::array<uint8_t, 32> bytes{};
+    static CompressedEdwardsY identity() { CompressedEdwardsY c; c.bytes[0] = 1; return c; }   // edwards.rs:273-283
+    std::optional<EdwardsPoint> decompress() const                          // edwards.rs:313-326
+    {
+        uint64_t o[20];
+        uint8_t ok = 0;
+        Backend::check(zc_ed_decompress(Backend::ctx(), bytes.data(), o, &ok, 1), "zc_ed_decompress");
+        if (!ok) return std::nullopt;
+        return EdwardsPoint::unflat(o);
+    }
+    bool operator==(const CompressedEdwardsY& o) const { return bytes == o.bytes; }
+};
+inline CompressedEdwardsY EdwardsPoint::compress() const                    // edwards.rs:613-629
+{
+    uint64_t a[20];
+    CompressedEdwardsY c;
+    uint8_t ok = 0;
+    flat(a);
+    Backend::check(zc_ed_compress(Backend::ctx(), a, c.bytes.data(), &ok, 1), "zc_ed_compress");
+    if (!ok) throw std::domain_error("compress: point has no affine form / x^2 is not a square");   // unwrap()/assert! panics
+    return c;
+}
+
+inline EdwardsPoint mul_by_pow_2(const EdwardsPoint& p, uint64_t k)         // edwards.rs:186-191
+{
+    uint64_t a[20], o[20];
+    p.flat(a);
+    Backend::check(zc_ed_mul_by_pow_2(Backend::ctx(), a, k, o, 1), "zc_ed_mul_by_pow_2");
+    return EdwardsPoint::unflat(o);
+}
+inline EdwardsPoint mul_by_cofactor(const EdwardsPoint& p)                  // edwards.rs:174-179
+{
+    uint64_t a[20], o[20];
+    p.flat(a);
+    Backend::check(zc_ed_mul_by_cofactor(Backend::ctx(), a, o, 1), "zc_ed_mul_by_cofactor");
+    return EdwardsPoint::unflat(o);
+}
+
+struct RistrettoPoint {
+    EdwardsPoint p;                                                         // RistrettoPoint(pub EdwardsPoint)
+    static RistrettoPoint identity() { return {EdwardsPoint::identity()}; }
+    RistrettoPoint operator+(const RistrettoPoint& q) const { return {p + q.p}; }
+    RistrettoPoint operator-(const RistrettoPoint& q) const { return {p + (-q.p)}; }        // ristretto.rs:291-293
+    RistrettoPoint operator-() const { return {-p}; }
+    RistrettoPoint double_() const { return {p.double_()}; }
+    RistrettoPoint operator*(const Scalar& k) const { return {p * k}; }
+    bool operator==(const RistrettoPoint& q) const                          // ristretto.rs:166-176
+    {
+        uint64_t a[20], b[20];
+        uint8_t e = 0;
+        p.flat(a); q.p.flat(b);
+        Backend::check(zc_ris_eq(Backend::ctx(), a, b, &e, 1), "zc_ris_eq");
+        return e != 0;
+    }
+    inline CompressedRistretto compress() const;
+};
+struct CompressedRistretto {
+    std::array<uint8_t, 32> bytes{};
+    static CompressedRistretto identity() { return {}; }
+    std::optional<RistrettoPoint> decompress() const                        // ristretto.rs:96-154
+    {
+        uint64_t o[20];
+        uint8_t ok = 0;
+        Backend::check(zc_ris_decompress(Backend::ctx(), bytes.data(), o, &ok, 1), "zc_ris_decompress");
+        if (!ok) return std::nullopt;
+        return RistrettoPoint{EdwardsPoint::unflat(o)};
+    }
+    bool operator==(const CompressedRistretto& o) const { return bytes == o.bytes; }
+};
+inline CompressedRistretto RistrettoPoint::compress() const                 // ristretto.rs:398-425
+{
+    uint64_t a[20];
+    CompressedRistretto c;
+    p.flat(a);
+    Backend::check(zc_ris_compress(Backend::ctx(), a, c.bytes.data(), 1), "zc_ris_compress");
+    return c;
+}
+inline RistrettoPoint operator*(const Scalar& k, const RistrettoPoint& p) { return p * k; }   // ristretto.rs:346-360
+
+// ---- batch API (what a caller with many elements should use) -------------------------------
+inline std::vector<EdwardsPoint> mul_batch(const std::vector<EdwardsPoint>& ps, const std::vector<Scalar>& ks)
+{
+    if (ps.size() != ks.size()) throw std::invalid_argument("mul_batch: size mismatch");
+    std::vector<uint64_t> p(ps.size() * 20), k(ks.size() * 5), o(ps.size() * 20);
+    for (size_t i = 0; i < ps.size(); i++) {
+        ps[i].flat(&p[20 * i]);
+        std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    }
+    Backend::check(zc_ed_scalar_mul(Backend::ctx(), p.data(), k.data(), o.data(), ps.size(), ZC_SCALAR_MUL_STRICT), "zc_ed_scalar_mul");
+    std::vector<EdwardsPoint> out(ps.size());
+    for (size_t i = 0; i < ps.size(); i++) out[i] = EdwardsPoint::unflat(&o[20 * i]);
+    return out;
+}
+inline std::vector<FieldElement> mul_batch(const std::vector<FieldElement>& a, const std::vector<FieldElement>& b)
+{
+    if (a.size() != b.size()) throw std::invalid_argument("mul_batch: size mismatch");
+    std::vector<uint64_t> x(a.size() * 5), y(a.size() * 5), o(a.size() * 5);
+    for (size_t i = 0; i < a.size(); i++) {
+        std::memcpy(&x[5 * i], a[i].l.data(), 40);
+        std::memcpy(&y[5 * i], b[i].l.data(), 40);
+    }
+    Backend::check(zc_fe_mul(Backend::ctx(), x.data(), y.data(), o.data(), a.size()), "zc_fe_mul");
+    std::vector<FieldElement> out(a.size());
+    for (size_t i = 0; i < a.size(); i++) std::memcpy(out[i].l.data(), &o[5 * i], 40);
+    return out;
+}
+inline std::vector<std::optional<CompressedRistretto>> ristretto_roundtrip_mul_batch(
+    const std::vector<CompressedRistretto>& enc, const std::vector<Scalar>& ks)
+{
+    if (enc.size() != ks.size()) throw std::invalid_argument("size mismatch");
+    std::vector<uint8_t> in(enc.size() * 32), out(enc.size() * 32), ok(enc.size());
+    std::vector<uint64_t> k(ks.size() * 5);
+    for (size_t i = 0; i < enc.size(); i++) {
+        std::memcpy(&in[32 * i], enc[i].bytes.data(), 32);
+        std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    }
+    Backend::check(zc_ris_roundtrip_mul(Backend::ctx(), in.data(), k.data(), out.data(), ok.data(), enc.size()), "zc_ris_roundtrip_mul");
+    std::vector<std::optional<CompressedRistretto>> r(enc.size());
+    for (size_t i = 0; i < enc.size(); i++)
+        if (ok[i]) {
+            CompressedRistretto c;
+            std::memcpy(c.bytes.data(), &out[32 * i], 32);
+            r[i] = c;
+        }
+    return r;
+}
+
+namespace constants {
+// src/backend/u64/constants.rs:188-211
+inline EdwardsPoint BASEPOINT()
+{
+    return {FieldElement(std::array<uint64_t, 5>{276718085098056ull, 1646536057461434ull, 2704687245600312ull, 2630386667454967ull, 13476148227069ull}),
+            FieldElement(std::array<uint64_t, 5>{1303868825475266ull, 3250718520537114ull, 2702159777242978ull, 2702159776422297ull, 10555311626649ull}),
+            FieldElement::one(),
+            FieldElement(std::array<uint64_t, 5>{3634527586288175ull, 2006028620404053ull, 3424252198034825ull, 2478951925947079ull, 4567251727358ull})};
+}
+inline RistrettoPoint RISTRETTO_BASEPOINT() { return {BASEPOINT()}; }
+inline Scalar L() { return Scalar(std::array<uint64_t, 5>{1129677152307299ull, 1363544697812651ull, 714439ull, 0, 2199023255552ull}); }   // :8-9
+inline FieldElement EDWARDS_D() { return FieldElement(std::array<uint64_t, 5>{3304133203739795ull, 2446467598308289ull, 1534112949566882ull, 2032729967918914ull, 2313225441931ull}); }  // :86-92
+}  // namespace constants
+
+}  // namespace zerocaf

@@ -1,0 +1,120 @@
+// C++ host-mirror tests: the reference's own unit tests, re-expressed on zerocaf.hpp
+// (dusk_zerocaf_amd/include/zerocaf.hpp over the C ABI).  Names in comments are the
+// reference test functions (src/backend/u64/field.rs:1136-1555, scalar.rs:788-1052,
+// src/edwards.rs:1357-1617, src/ristretto.rs:533-720).  Needs a GPU.
+#include <cstdio>
+#include <cstdlib>
+#include "../../dusk_zerocaf_amd/include/zerocaf.hpp"
+
+using namespace zerocaf;
+static int failures = 0;
+#define CHECK(...) do { if (!(__VA_ARGS__)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #__VA_ARGS__); failures++; } } while (0)
+typedef std::array<uint64_t, 5> L5;
+static bool limbs_eq(const FieldElement& a, const L5& b) { return a.l == b; }
+
+static std::array<uint8_t, 32> hex32(const char* h)
+{
+    std::array<uint8_t, 32> b{};
+    for (int i = 0; i < 32; i++) { unsigned v; std::sscanf(h + 2 * i, "%2x", &v); b[i] = (uint8_t)v; }
+    return b;
+}
+
+int main()
+{
+    // ---- field.rs KATs (:939-1132)
+    const FieldElement A(L5{0, 0, 0, 2, 0});
+    const FieldElement B(L5{2766226127823335ull, 4237835465749098ull, 4503599626623787ull, 4503599627370493ull, 2199023255551ull});
+    const FieldElement C(L5{2009874587549ull, 0, 0, 0, 0});
+    CHECK(limbs_eq(FieldElement::minus_one() + FieldElement::one(), L5{0, 0, 0, 0, 0}));                   // addition_with_modulo
+    CHECK(limbs_eq(A + B, L5{2766226127823335ull, 4237835465749098ull, 4503599626623787ull, 4503599627370495ull, 2199023255551ull}));
+    CHECK(limbs_eq(A - B, L5{2409288332882438ull, 4182428486726422ull, 2114509ull, 4ull, 15393162788864ull})); // subtraction_with_mod
+    CHECK(limbs_eq(A * B, L5{2201910185007838ull, 1263014888683320ull, 1977367609994094ull, 4238575041099341ull, 2233595300724ull})); // mul_with_modulo
+    CHECK(limbs_eq(A * C, L5{0, 0, 0, 4019749175098ull, 0}));                                              // mul_without_modulo
+    CHECK(limbs_eq(A.square(), L5{671914833335277ull, 423018350096769ull, 2042999080933985ull, 4503598226741381ull, 17592186044415ull}));
+    CHECK(limbs_eq(FieldElement::zero().square(), L5{0, 0, 0, 0, 0}) && limbs_eq(FieldElement::one().square(), L5{1, 0, 0, 0, 0}));
+    CHECK(limbs_eq(-A, L5{671914833335277ull, 3916664325105025ull, 1367801ull, 4503599627370494ull, 17592186044415ull}));
+    CHECK(limbs_eq(A.inverse(), L5{1289905446467013ull, 1277206401232501ull, 2632844239031511ull, 61125669693438ull, 17393375336657ull})); // savas_koc_inverse
+    CHECK(limbs_eq(C.inverse(), L5{623443786605621ull, 2862023947424023ull, 16740108872882ull, 4368084563887202ull, 16954962737206ull}));
+    bool threw = false;
+    try { (void)FieldElement::zero().inverse(); } catch (const std::domain_error&) { threw = true; }
+    CHECK(threw);                                                                                           // inverse(0) panics
+    CHECK((-FieldElement(86649) / FieldElement(86650)) ==
+          FieldElement(L5{939392471225133ull, 587442007554368ull, 4497154776428662ull, 4184267646867733ull, 2921744366591ull})); // division
+    CHECK((-FieldElement(126296) / FieldElement(126297)) == constants::EDWARDS_D());                       // doc-test src/field.rs:51
+    CHECK(-(FieldElement(27).inv_sqrt().second) ==
+          FieldElement(L5{2352169988867884ull, 2446401460527425ull, 986927416739735ull, 989222758354178ull, 11393383279360ull})); // inv_sqrt
+    const std::array<uint8_t, 32> m1b = {236, 211, 245, 92, 26, 99, 18, 88, 214, 156, 247, 162, 222, 249, 222, 20, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16};
+    CHECK(FieldElement::from_bytes(m1b).l == FieldElement::minus_one().l && FieldElement::minus_one().to_bytes() == m1b);
+
+    // ---- scalar.rs KATs (:681-784)
+    const Scalar X(L5{4503599627370495ull, 4503599627370495ull, 4503599627370495ull, 4503599627370495ull, 4398046511103ull});
+    const Scalar Y(L5{138340288859536ull, 461913478537005ull, 1182880083788836ull, 1688835920473363ull, 1743782656037ull});
+    CHECK((X * Y).l == L5{3955754814270951ull, 1675310998682037ull, 4396625830536378ull, 1174212537684658ull, 176498809098ull}); // scalar_mul
+    CHECK(Y.square().l == L5{3511508334592158ull, 913859277470939ull, 3383393792942685ull, 3918279098243301ull, 1168230887094ull});
+    CHECK((Y * Scalar::one()).l == Y.l && (Y * Scalar::zero()).l == Scalar::zero().l);
+    CHECK(Scalar::two_pow_k(249).l == L5{0, 0, 0, 0, 2199023255552ull});
+    threw = false;
+    try { (void)Scalar::two_pow_k(250); } catch (const std::domain_error&) { threw = true; }
+    CHECK(threw);
+
+    // ---- edwards.rs fixtures (:1145-1353)
+    const EdwardsPoint P1{FieldElement(L5{13, 0, 0, 0, 0}),
+                          FieldElement(L5{606320128494542ull, 1597163540666577ull, 1835599237877421ull, 1667478411389512ull, 3232679738299ull}),
+                          FieldElement::one(),
+                          FieldElement(L5{2034732376387996ull, 3922598123714460ull, 1344791952818393ull, 3662820838581677ull, 6840464509059ull})};
+    const EdwardsPoint P2{FieldElement(L5{67, 0, 0, 0, 0}),
+                          FieldElement(L5{2369245568431362ull, 2665603790611352ull, 3317390952748653ull, 1908583331312524ull, 8011773354506ull}),
+                          FieldElement::one(),
+                          FieldElement(L5{3474019263728064ull, 2548729061993416ull, 1588812051971430ull, 1774293631565269ull, 9023233419450ull})};
+    const EdwardsPoint P4 = P1 + P2;                                                                        // extended_point_addition (limb-exact)
+    CHECK(limbs_eq(P4.X, L5{28731243678497ull, 3605893500953713ull, 4417389530006141ull, 299092414682919ull, 4656166963268ull}));
+    CHECK(limbs_eq(P4.Z, L5{3678126740275983ull, 2102367182843193ull, 1215780564383894ull, 577880234309233ull, 3967832577760ull}));
+    CHECK(limbs_eq(P4.T, L5{1187490310723625ull, 475595246262913ull, 1092363334429875ull, 285623496107549ull, 15708045001361ull}));
+    CHECK(P1.double_() == P1 + P1);                                                                         // extended_point_doubling
+    CHECK(EdwardsPoint::identity().double_() == EdwardsPoint::identity());
+    CHECK(-EdwardsPoint::identity() == EdwardsPoint::identity());                                           // extended_coords_neg_identity
+    CHECK(P1 * Scalar(8) == P1.double_().double_().double_());                                              // extended_double_and_add
+    CHECK(mul_by_cofactor(P1) == P1 * Scalar(8));                                                           // doc-test edwards.rs:54-57
+    const CompressedEdwardsY c1 = P1.compress();                                                            // point_compression
+    const std::array<uint8_t, 32> p1c = {206, 11, 225, 231, 113, 39, 18, 141, 213, 215, 201, 201, 90, 173, 14, 134, 192, 119, 133, 134, 164, 26, 38, 1, 201, 94, 187, 59, 186, 170, 240, 2};
+    CHECK(c1.bytes == p1c);
+    CHECK(c1.decompress().has_value() && *c1.decompress() == P1);                                           // point_decompression
+    CompressedEdwardsY bad;
+    bad.bytes = {250, 144, 188, 47, 13, 101, 118, 114, 201, 185, 169, 115, 255, 111, 40, 25, 69, 105, 170, 255, 113, 65, 120, 126, 170, 192, 48, 109, 112, 20, 221, 149};
+    CHECK(!bad.decompress().has_value());
+    CHECK(constants::BASEPOINT() * constants::L() == EdwardsPoint::identity());                             // unique_basepoint_test
+
+    // ---- ristretto.rs (:533-663)
+    static const char* enc[16] = {
+        "0000000000000000000000000000000000000000000000000000000000000000", "0200000000000000000000000000000000000000000000000000000000000000",
+        "abe4ea98eaaeda5a9c63879cb3c4d9b4a01ed31ac383acefd7ed49861e1a8002", "1064fe35b16525f90f1d2f7d3dc448ba31a118f136c53eed88c2e951f1832907",
+        "a826cf66461dea21e51187dddd8753299b726a7d4217cb75758aefbf5a2d4f01", "4d2e0705a9b47d122f98bd74808d386cf1691bc5407af703dd0c4808038b7f07",
+        "f3a3592fde5fa05a881b80b4e732b37c32c7f684a5be33cdb8b7bdaf53db6f04", "51626c7960da63010efc5e064e62962f158f59928914fc108257ec2653745e01",
+        "d5f8144c1b04954291785be578633a79131752e82afb990bd4a25b41cbd49001", "1372ed81add54633970746cd4b38ceb8a3e538b916288ac3d7c0dfbd54a42b06",
+        "a83d7a262a80926724a0beb75a5f26e9a622205e6a64730e14ce64c4b2acf704", "a6b2712a6e586ab552f7bcf438168304b8b8a3f3b2852a06ae183e6303406503",
+        "7876266b939b889c1da827a76da5c220eb1ff934472d35de60c9e4c3528fcc06", "11a0f75ab351572b572c38bf073b076aa964cdff70d53ad7588174dae2729306",
+        "64f2fb80b45fbf73793e9e8e509f98848ecdb452c98c83c55c5c31fb233d9907", "1de5afbe9fd279f1651306d8ac0f68f0cb2689609ccfe8db1636f9481a33e205"};
+    RistrettoPoint P = RistrettoPoint::identity();
+    const RistrettoPoint Bp = constants::RISTRETTO_BASEPOINT();
+    for (int i = 0; i < 16; i++) {                                                                          // valid_encoding_test_vectors
+        CHECK(P.compress().bytes == hex32(enc[i]));
+        P = P + Bp;
+    }
+    const auto dec = Bp.compress().decompress();                                                            // basepoint_compr_decompr
+    CHECK(dec.has_value() && *dec == Bp);
+    const EdwardsPoint o4 = Bp.p - dec->p;                                                                  // four_torsion_diff
+    CHECK(mul_by_pow_2(o4, 2).compress() == CompressedEdwardsY::identity());
+    CHECK(Scalar(5) * Bp == Bp * Scalar(5));
+
+    // ---- batch API agrees with the single-element operators
+    std::vector<EdwardsPoint> ps = {P1, P2, P4, constants::BASEPOINT()};
+    std::vector<Scalar> ks = {Scalar(8), Y, X, Scalar::minus_one()};
+    const auto outs = mul_batch(ps, ks);
+    for (size_t i = 0; i < ps.size(); i++) {
+        const EdwardsPoint s = ps[i] * ks[i];
+        CHECK(outs[i].X.l == s.X.l && outs[i].Y.l == s.Y.l && outs[i].Z.l == s.Z.l && outs[i].T.l == s.T.l);
+    }
+    if (failures) { std::printf("%d FAILURES\n", failures); return 1; }
+    std::printf("zerocaf.hpp: all reference-style checks passed\n");
+    return 0;
+}
