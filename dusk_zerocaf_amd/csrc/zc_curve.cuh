@@ -99,6 +99,55 @@ ZC_DI bool fp_mod_sqrt(fe& x, const fe& a, bool sign)
     return ok;
 }
 
+ZC_DI void load5(u64 (&l)[5], const u64* __restrict__ p)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) l[i] = p[i];
+}
+ZC_DI void store5(u64* __restrict__ p, const u64 (&l)[5])
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) p[i] = l[i];
+}
+
+ZC_DI bool limbs52_all_zero(const u64 (&l)[5]) { return (l[0] | l[1] | l[2] | l[3] | l[4]) == 0; }
+
+// One lane's share of the batched inversion (Montgomery's trick over `c` consecutive
+// elements starting at `lo`; see k_fe_invert_chunked in zc_kernels.cuh).
+ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, int c)
+{
+    const int cnt = (int)((n - lo < (size_t)c) ? (n - lo) : (size_t)c);
+    const fe neutral = fe_one_m<FP>();
+    fe acc = neutral;
+    for (int j = 0; j < cnt; j++) {
+        u64 l[5];
+        load5(l, a + 5 * (lo + j));
+        const fe x = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
+        u32* slot = reinterpret_cast<u32*>(out + 5 * (lo + j));
+#pragma unroll
+        for (int w = 0; w < 9; w++) slot[w] = acc.v[w];    // acc_{j-1} (R mod p for j = 0)
+        acc = fp_mul(acc, x);
+    }
+    // plain inverse of the register value: fp_invert returns acc^-1 * R^2
+    fe inv = mont_from<FP>(mont_from<FP>(fp_invert(acc)));
+    for (int j = cnt - 1; j >= 0; j--) {
+        u64 l[5], r[5];
+        load5(l, a + 5 * (lo + j));
+        const bool z = limbs52_all_zero(l);
+        const fe x = fe_select(z, neutral, fe_from_limbs52(l));
+        const u32* slot = reinterpret_cast<const u32*>(out + 5 * (lo + j));
+        fe pre;
+#pragma unroll
+        for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
+        const fe res = fp_mul(inv, pre);                    // a_j^-1, plain, < 3p
+        inv = fp_mul(inv, x);
+        fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(res)));
+        if (z) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
+        store5(out + 5 * (lo + j), r);
+        if (ok) ok[lo + j] = z ? 0 : 1;
+    }
+}
+
 // ---------------------------------------------------------------- points
 ZC_DI pt pt_identity()                                            // edwards.rs:381-391
 {

@@ -48,76 +48,122 @@ ZC_DI void add52(u64 (&r)[5], const u64 (&a)[5], const u64 (&b)[5], const u64 (&
     }
     sub52(r, s, m, m);
 }
-ZC_DI void load5(u64 (&l)[5], const u64* __restrict__ p)
+// ------------------------------------------------------------------ LDS-staged element I/O
+// The element-wise kernels are HBM-bound (80-120 B per element).  A lane's 40-byte
+// record is strided in memory, so the block's 256 records (10 KB, contiguous) are moved with
+// coalesced 16-byte loads/stores through LDS and each lane reads/writes its own record there
+// with five ds_read_b64 / ds_write_b64 (stride 40 B = 10 banks: conflict-free in both 32-lane
+// halves).  Requires 16-byte aligned array bases (checked by the host; plain fallback kernel
+// with per-lane global accesses otherwise).
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+ZC_DI void coop_load40(u64* __restrict__ lds, const u64* __restrict__ g, int cnt)
 {
-#pragma unroll
-    for (int i = 0; i < 5; i++) l[i] = p[i];
+    const int nvec = (cnt * 5) >> 1;                       // 16-byte vectors
+    const u64x2* gv = reinterpret_cast<const u64x2*>(g);
+    u64x2* lv = reinterpret_cast<u64x2*>(lds);
+    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) lv[v] = __builtin_nontemporal_load(gv + v);
+    if ((cnt & 1) && threadIdx.x == 0) lds[cnt * 5 - 1] = g[cnt * 5 - 1];
 }
-ZC_DI void store5(u64* __restrict__ p, const u64 (&l)[5])
+ZC_DI void coop_store40(u64* __restrict__ g, const u64* __restrict__ lds, int cnt)
 {
-#pragma unroll
-    for (int i = 0; i < 5; i++) p[i] = l[i];
+    const int nvec = (cnt * 5) >> 1;
+    u64x2* gv = reinterpret_cast<u64x2*>(g);
+    const u64x2* lv = reinterpret_cast<const u64x2*>(lds);
+    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) __builtin_nontemporal_store(lv[v], gv + v);
+    if ((cnt & 1) && threadIdx.x == 0) g[cnt * 5 - 1] = lds[cnt * 5 - 1];
 }
 
-template <class F, int OP>   // OP: 0 add, 1 sub, 2 neg
-ZC_DI void addsub_body(const u64* a, const u64* b, u64* out, size_t n)
+// Op::apply(r, x, y): five-limb radix-2^52 in/out.  NIN = number of input arrays (1 or 2).
+template <class Op, int NIN, bool STAGED>
+ZC_DI void elementwise_body(const u64* a, const u64* b, u64* out, size_t n)
 {
-    const size_t i = gid();
-    if (i >= n) return;
-    u64 m[5], x[5], y[5], r[5];
-    limbs52_of_modulus<F>(m);
-    load5(x, a + 5 * i);
-    if (OP == 2) {
+    if (STAGED) {
+        __shared__ __attribute__((aligned(16))) u64 sa[ZC_BLOCK * 5];
+        __shared__ __attribute__((aligned(16))) u64 sb[(NIN == 2 ? ZC_BLOCK : 1) * 5];
+        const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
+        const int cnt = (int)((n - base < (size_t)ZC_BLOCK) ? (n - base) : (size_t)ZC_BLOCK);
+        coop_load40(sa, a + 5 * base, cnt);
+        if (NIN == 2) coop_load40(sb, b + 5 * base, cnt);
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < cnt) {
+            u64 x[5], y[5], r[5];
 #pragma unroll
-        for (int j = 0; j < 5; j++) { y[j] = x[j]; x[j] = 0; }
+            for (int j = 0; j < 5; j++) {
+                x[j] = sa[t * 5 + j];
+                y[j] = (NIN == 2) ? sb[t * 5 + j] : 0;
+            }
+            Op::apply(r, x, y);
+#pragma unroll
+            for (int j = 0; j < 5; j++) sa[t * 5 + j] = r[j];   // own slot only
+        }
+        __syncthreads();
+        coop_store40(out + 5 * base, sa, cnt);
     } else {
-        load5(y, b + 5 * i);
+        const size_t i = gid();
+        if (i >= n) return;
+        u64 x[5], y[5], r[5];
+        load5(x, a + 5 * i);
+        if (NIN == 2) load5(y, b + 5 * i);
+        else {
+#pragma unroll
+            for (int j = 0; j < 5; j++) y[j] = 0;
+        }
+        Op::apply(r, x, y);
+        store5(out + 5 * i, r);
     }
-    if (OP == 0) add52(r, x, y, m);
-    else sub52(r, x, y, m);
-    store5(out + 5 * i, r);
 }
-ZC_KERNEL void k_fe_add(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModP, 0>(a, b, out, n); }
-ZC_KERNEL void k_fe_sub(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModP, 1>(a, b, out, n); }
-ZC_KERNEL void k_fe_neg(const u64* a, u64* out, size_t n) { addsub_body<ModP, 2>(a, nullptr, out, n); }
-ZC_KERNEL void k_sc_add(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModL, 0>(a, b, out, n); }
-ZC_KERNEL void k_sc_sub(const u64* a, const u64* b, u64* out, size_t n) { addsub_body<ModL, 1>(a, b, out, n); }
-ZC_KERNEL void k_sc_neg(const u64* a, u64* out, size_t n) { addsub_body<ModL, 2>(a, nullptr, out, n); }
 
-// ------------------------------------------------------------------ mul / square
-// plain operands -> a*b mod N canonical: (a*R) * b / R, then canonicalise (< 3N)
-template <class F>
-ZC_DI void store_plain_canon(u64* __restrict__ o, const fe& x)   // x plain value < 3N, normalized
-{
-    u64 l[5];
-    fe_to_limbs52(l, fe_cond_sub_n<F>(fe_cond_sub_n<F>(x)));
-    store5(o, l);
-}
-template <class F>
-ZC_DI void mul_body(const u64* a, const u64* b, u64* out, size_t n)
-{
-    const size_t i = gid();
-    if (i >= n) return;
-    u64 x[5], y[5];
-    load5(x, a + 5 * i);
-    load5(y, b + 5 * i);
-    const fe am = mont_to<F>(fe_from_limbs52(x));
-    store_plain_canon<F>(out + 5 * i, mont_mul<F>(am, fe_from_limbs52(y)));
-}
-template <class F>
-ZC_DI void sqr_body(const u64* a, u64* out, size_t n)
-{
-    const size_t i = gid();
-    if (i >= n) return;
-    u64 x[5];
-    load5(x, a + 5 * i);
-    const fe s = mont_sqr<F>(fe_from_limbs52(x));          // a^2 / R
-    store_plain_canon<F>(out + 5 * i, mont_mul<F>(s, fe_const<F>(F::RR)));
-}
-ZC_KERNEL void k_fe_mul(const u64* a, const u64* b, u64* out, size_t n) { mul_body<ModP>(a, b, out, n); }
-ZC_KERNEL void k_sc_mul(const u64* a, const u64* b, u64* out, size_t n) { mul_body<ModL>(a, b, out, n); }
-ZC_KERNEL void k_fe_square(const u64* a, u64* out, size_t n) { sqr_body<ModP>(a, out, n); }
-ZC_KERNEL void k_sc_square(const u64* a, u64* out, size_t n) { sqr_body<ModL>(a, out, n); }
+template <class F> struct OpAdd {
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&y)[5]) { u64 m[5]; limbs52_of_modulus<F>(m); add52(r, x, y, m); }
+};
+template <class F> struct OpSub {
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&y)[5]) { u64 m[5]; limbs52_of_modulus<F>(m); sub52(r, x, y, m); }
+};
+template <class F> struct OpNeg {
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&)[5])
+    {
+        u64 m[5], z[5] = {0, 0, 0, 0, 0};
+        limbs52_of_modulus<F>(m);
+        sub52(r, z, x, m);
+    }
+};
+// plain operands -> a*b mod N canonical: (a*R) * b / R, then canonicalise (value < 3N)
+template <class F> struct OpMul {
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&y)[5])
+    {
+        const fe am = mont_to<F>(fe_from_limbs52(x));
+        const fe p = mont_mul<F>(am, fe_from_limbs52(y));
+        fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(p)));
+    }
+};
+template <class F> struct OpSqr {
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&)[5])
+    {
+        const fe s = mont_sqr<F>(fe_from_limbs52(x));       // a^2 / R
+        const fe p = mont_mul<F>(s, fe_const<F>(F::RR));
+        fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(p)));
+    }
+};
+
+#define ZC_ELEMENTWISE2(name, OP)                                                                       \
+    ZC_KERNEL void name(const u64* a, const u64* b, u64* out, size_t n) { elementwise_body<OP, 2, true>(a, b, out, n); }   \
+    ZC_KERNEL void name##_plain(const u64* a, const u64* b, u64* out, size_t n) { elementwise_body<OP, 2, false>(a, b, out, n); }
+#define ZC_ELEMENTWISE1(name, OP)                                                                       \
+    ZC_KERNEL void name(const u64* a, u64* out, size_t n) { elementwise_body<OP, 1, true>(a, nullptr, out, n); }            \
+    ZC_KERNEL void name##_plain(const u64* a, u64* out, size_t n) { elementwise_body<OP, 1, false>(a, nullptr, out, n); }
+
+ZC_ELEMENTWISE2(k_fe_add, OpAdd<ModP>)
+ZC_ELEMENTWISE2(k_fe_sub, OpSub<ModP>)
+ZC_ELEMENTWISE1(k_fe_neg, OpNeg<ModP>)
+ZC_ELEMENTWISE2(k_sc_add, OpAdd<ModL>)
+ZC_ELEMENTWISE2(k_sc_sub, OpSub<ModL>)
+ZC_ELEMENTWISE1(k_sc_neg, OpNeg<ModL>)
+ZC_ELEMENTWISE2(k_fe_mul, OpMul<ModP>)
+ZC_ELEMENTWISE2(k_sc_mul, OpMul<ModL>)
+ZC_ELEMENTWISE1(k_fe_square, OpSqr<ModP>)
+ZC_ELEMENTWISE1(k_sc_square, OpSqr<ModL>)
 
 // ------------------------------------------------------------------ invert / sqrt_ratio_i
 ZC_KERNEL void k_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
@@ -128,6 +174,21 @@ ZC_KERNEL void k_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
     const bool nz = !fp_is_zero(x);
     fe_store_canon<FP>(out + 5 * i, fp_invert(x));         // 0^(p-2) = 0
     if (ok) ok[i] = nz ? 1 : 0;
+}
+
+// Batched inversion, Montgomery's trick per lane: lane g owns the `c` consecutive elements
+// [g*c, g*c+c).  The reference inverts one element at a time with ~357 field Mul each
+// (field.rs:854-925); here a chunk shares ONE fixed-schedule exponentiation, so an element
+// costs 3 Montgomery multiplications + 300/c.  The plain inputs are used directly as
+// Montgomery residues (register value x stands for x/R): with acc_j = a_1...a_j R^-(j-1) and
+// I_j = acc_j^-1 (plain), a_j^-1 = montmul(I_j, acc_{j-1}) and I_{j-1} = montmul(I_j, a_j) --
+// no per-element domain conversion at all.  Prefix products are parked in the output records
+// (36 of the 40 bytes) between the two sweeps, so `out` must not alias `a`.
+// Zero elements (the reference panics) take the neutral value R mod p and yield 0 / ok = 0.
+ZC_KERNEL void k_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
+{
+    const size_t lo = gid() * (size_t)c;
+    if (lo < n) fe_invert_chunk(a, out, ok, n, lo, c);
 }
 ZC_KERNEL void k_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* was_square, size_t n)
 {
@@ -283,15 +344,98 @@ ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int tid, in
     return Q;
 }
 
+// ---- lane balancing -------------------------------------------------------------------
+// A wave needs max over its 64 lanes of (bitlen - 1 + popcount) unified steps.  For random
+// scalars that maximum is ~6 % above the mean, so the batch is first ordered by that cost with
+// a counting sort (cost < 1024 bins) and wave w processes the elements idx[64w .. 64w+63], which
+// then have (nearly) equal cost.  Results are scattered back through the same index, so the
+// output order is unchanged.  Three tiny kernels (~tens of microseconds at 2^20).
+constexpr int ZC_COST_BINS = 1024;
+
+ZC_DI u32 scalar_cost(const u64 (&l)[5])
+{
+    u32 bits = 0, pop = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const u64 x = l[j] & M52;
+        pop += __builtin_popcountll(x);
+        if (x) bits = 52 * j + (64 - __builtin_clzll(x));
+    }
+    return bits ? bits - 1 + pop : 0;                    // <= 259 + 260
+}
+// hist[c] = number of scalars of cost c (LDS histogram per block, one global atomic per non-empty bin)
+ZC_KERNEL void k_sm_cost_hist(const u64* k, u32* hist, size_t n)
+{
+    __shared__ u32 h[ZC_COST_BINS];
+    for (int b = threadIdx.x; b < ZC_COST_BINS; b += ZC_BLOCK) h[b] = 0;
+    __syncthreads();
+    const size_t i = gid();
+    if (i < n) {
+        u64 l[5];
+        load5(l, k + 5 * i);
+        atomicAdd(&h[scalar_cost(l)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ZC_COST_BINS; b += ZC_BLOCK)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+// exclusive scan over the bins, most expensive first (long waves start early); single block
+ZC_KERNEL void k_sm_cost_scan(u32* hist)
+{
+    __shared__ u32 part[ZC_BLOCK];
+    const int t = threadIdx.x;
+    u32 v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                        // thread t owns descending bins 1023-4t .. 1020-4t
+        v[j] = hist[ZC_COST_BINS - 1 - (4 * t + j)];
+        sum += v[j];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < ZC_BLOCK; d <<= 1) {
+        const u32 x = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    u32 base = part[t] - sum;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        hist[ZC_COST_BINS - 1 - (4 * t + j)] = base;
+        base += v[j];
+    }
+}
+// idx[offset[cost]++] = i, with block-level aggregation of the global atomics
+ZC_KERNEL void k_sm_cost_scatter(const u64* k, u32* offsets, u32* idx, size_t n)
+{
+    __shared__ u32 cnt[ZC_COST_BINS];
+    __shared__ u32 base[ZC_COST_BINS];
+    for (int b = threadIdx.x; b < ZC_COST_BINS; b += ZC_BLOCK) cnt[b] = 0;
+    __syncthreads();
+    const size_t i = gid();
+    u32 c = 0, rank = 0;
+    if (i < n) {
+        u64 l[5];
+        load5(l, k + 5 * i);
+        c = scalar_cost(l);
+        rank = atomicAdd(&cnt[c], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ZC_COST_BINS; b += ZC_BLOCK)
+        if (cnt[b]) base[b] = atomicAdd(&offsets[b], cnt[b]);
+    __syncthreads();
+    if (i < n) idx[base[c] + rank] = (u32)i;
+}
+
 // k_stride = 5 (one scalar per point) or 0 (one scalar for the whole batch:
-// mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191)
-ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, size_t n)
+// mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191).  idx: optional cost-sorted permutation.
+ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
-    const size_t ii = valid ? i : 0;
+    const size_t ii = valid ? (idx ? (size_t)idx[i] : i) : 0;
     u64 l[5];
     load5(l, k + k_stride * ii);
     int nbits;
@@ -299,7 +443,7 @@ ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64*
     if (!valid) nbits = 0;
     const pt P = pt_load(p + 20 * ii);
     const pt Q = scalar_mul_unified(P, sk, tid, nbits);
-    if (valid) pt_store(out + 20 * i, Q);
+    if (valid) pt_store(out + 20 * ii, Q);
 }
 
 // ------------------------------------------------------------------ affine / eq / Edwards codec
@@ -368,13 +512,13 @@ ZC_KERNEL void k_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
     eq[i] = ris_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
 }
 // fused config-4 path: 32 B in -> registers -> 32 B out; the point never touches HBM
-ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, size_t n)
+ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, const u32* idx, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
-    const size_t ii = valid ? i : 0;
+    const size_t ii = valid ? (idx ? (size_t)idx[i] : i) : 0;
     u64 w[4], l[5];
     load_words256(w, in + 32 * ii);
     load5(l, k + 5 * ii);
@@ -387,8 +531,8 @@ ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out
     fe_to_words256(w, ris_compress(Q));
     if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
     if (valid) {
-        store_words256(out + 32 * i, w);
-        if (ok) ok[i] = dec ? 1 : 0;
+        store_words256(out + 32 * ii, w);
+        if (ok) ok[ii] = dec ? 1 : 0;
     }
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -46,6 +47,8 @@ struct DevState {
     size_t scratch_bytes[MAX_ARGS] = {};
     void* tmp[2] = {};                  // zc_msm partials
     size_t tmp_bytes[2] = {};
+    void* bal = nullptr;                // lane balancing: 1024 u32 bins + n u32 indices
+    size_t bal_bytes = 0;
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -101,7 +104,7 @@ int ensure(void** buf, size_t* have, size_t need)
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + zc::ZC_BLOCK - 1) / zc::ZC_BLOCK); }
 
-// Launch functor: receives device pointers in argument order, element count, stream.
+// Launch functor: receives device pointers in argument order, element count, device state.
 template <class Launch>
 int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch)
 {
@@ -135,7 +138,7 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch)
         HIP_TRY(hipSetDevice(ds->device));
         void* dptr[MAX_ARGS];
         for (int a = 0; a < nargs; a++) dptr[a] = const_cast<void*>(args[a].ptr);
-        launch(dptr, n, ds->s());
+        launch(dptr, n, *ds);
         HIP_TRY(hipGetLastError());
         return ZC_OK;
     }
@@ -162,7 +165,7 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch)
                 HIP_TRY(hipMemcpyAsync(dptr[a], src, bytes, hipMemcpyHostToDevice, ds.s()));
             }
         }
-        launch(dptr, cnt, ds.s());
+        launch(dptr, cnt, ds);
         HIP_TRY(hipGetLastError());
         for (int a = 0; a < nargs; a++) {
             if (!args[a].ptr || !args[a].is_out) continue;
@@ -186,21 +189,44 @@ inline Arg out_arg(void* p, size_t b) { return Arg{p, b, true, false}; }
 typedef void (*kbin_t)(const u64*, const u64*, u64*, size_t);
 typedef void (*kun_t)(const u64*, u64*, size_t);
 
-int binop(zc_ctx* ctx, kbin_t k, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// `k` moves records through LDS with 16-byte accesses and needs 16-byte aligned bases;
+// `k_plain` is the per-lane variant for arbitrarily (8-byte) aligned device pointers.
+int binop(zc_ctx* ctx, kbin_t k, kbin_t k_plain, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
 {
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     Arg args[3] = {in_arg(a, elt), in_arg(b, elt), out_arg(out, elt)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        kbin_t kk = (k_plain && !(aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]))) ? k_plain : k;
+        hipLaunchKernelGGL(kk, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
     });
 }
-int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
+int unop(zc_ctx* ctx, kun_t k, kun_t k_plain, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
 {
     REQUIRE(a); REQUIRE(out);
     Arg args[2] = {in_arg(a, elt), out_arg(out, elt)};
-    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (u64*)d[1], cnt);
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        kun_t kk = (k_plain && !(aligned16(d[0]) && aligned16(d[1]))) ? k_plain : k;
+        hipLaunchKernelGGL(kk, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
+}
+
+// Cost-sorted permutation for the unified-step kernels (see zc_kernels.cuh "lane balancing").
+// Returns nullptr (natural order) for small batches or when scratch cannot be had.
+constexpr size_t BALANCE_MIN_N = 1 << 14;
+const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt)
+{
+    if (cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
+    const size_t need = zc::ZC_COST_BINS * sizeof(zc::u32) + cnt * sizeof(zc::u32);
+    if (ensure(&D.bal, &D.bal_bytes, need) != ZC_OK) return nullptr;
+    zc::u32* hist = (zc::u32*)D.bal;
+    zc::u32* idx = hist + zc::ZC_COST_BINS;
+    if (hipMemsetAsync(hist, 0, zc::ZC_COST_BINS * sizeof(zc::u32), D.s()) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(zc::k_sm_cost_hist, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), k, hist, cnt);
+    hipLaunchKernelGGL(zc::k_sm_cost_scan, dim3(1), dim3(zc::ZC_BLOCK), 0, D.s(), hist);
+    hipLaunchKernelGGL(zc::k_sm_cost_scatter, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), k, hist, idx, cnt);
+    return idx;
 }
 
 int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, bool broadcast_k, uint64_t* out, size_t n)
@@ -208,9 +234,10 @@ int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, bool broa
     REQUIRE(p); REQUIRE(k); REQUIRE(out);
     Arg args[3] = {in_arg(p, 160), Arg{k, 40, false, broadcast_k}, out_arg(out, 160)};
     const size_t stride = broadcast_k ? 0 : 5;
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0],
-                           (const u64*)d[1], stride, (u64*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        const zc::u32* idx = broadcast_k ? nullptr : balance_index(D, (const u64*)d[1], cnt);
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
+                           (const u64*)d[1], stride, (u64*)d[2], idx, cnt);
     });
 }
 
@@ -276,6 +303,7 @@ int zc_ctx_destroy(zc_ctx* ctx)
             if (ds.scratch[a]) (void)hipFree(ds.scratch[a]);
         for (int a = 0; a < 2; a++)
             if (ds.tmp[a]) (void)hipFree(ds.tmp[a]);
+        if (ds.bal) (void)hipFree(ds.bal);
         if (ds.stream) (void)hipStreamDestroy(ds.stream);
     }
     delete ctx;
@@ -302,66 +330,74 @@ int zc_ctx_synchronize(zc_ctx* ctx)
 }
 
 // ---- FieldElement
-int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, a, b, o, n, 40); }
-int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, a, b, o, n, 40); }
-int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, a, b, o, n, 40); }
-int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
-int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40); }
+int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, zc::k_fe_add_plain, a, b, o, n, 40); }
+int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, zc::k_fe_sub_plain, a, b, o, n, 40); }
+int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, zc::k_fe_mul_plain, a, b, o, n, 40); }
+int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, zc::k_fe_neg_plain, a, o, n, 40); }
+int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, zc::k_fe_square_plain, a, o, n, 40); }
 
 int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(a); REQUIRE(out);
     Arg args[3] = {in_arg(a, 40), out_arg(out, 40), out_arg(ok, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_fe_invert, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        // chunk length: keep >= 2 waves per SIMD busy (256 CUs x 4 SIMDs x 2 x 64 lanes), cap at 64
+        size_t c = cnt / 131072;
+        if (c > 64) c = 64;
+        if (c < 2 || d[0] == d[1]) {                       // tiny batch or in-place: one element per lane
+            hipLaunchKernelGGL(zc::k_fe_invert, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+        } else {
+            const size_t lanes = (cnt + c - 1) / c;
+            hipLaunchKernelGGL(zc::k_fe_invert_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt, (int)c);
+        }
     });
 }
 int zc_fe_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);
     Arg args[2] = {in_arg(in32, 32), out_arg(out, 40)};
-    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_from_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)nullptr, 0, cnt);
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_from_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)nullptr, 0, cnt);
     });
 }
 int zc_fe_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n)
 {
     REQUIRE(in); REQUIRE(out32);
     Arg args[2] = {in_arg(in, 40), out_arg(out32, 32)};
-    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_to_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (uint8_t*)d[1], cnt);
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_to_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
     });
 }
 int zc_fe_sqrt_ratio_i(zc_ctx* ctx, const uint64_t* u, const uint64_t* v, uint64_t* out, uint8_t* was_square, size_t n)
 {
     REQUIRE(u); REQUIRE(v); REQUIRE(out);
     Arg args[4] = {in_arg(u, 40), in_arg(v, 40), out_arg(out, 40), out_arg(was_square, 1)};
-    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_fe_sqrt_ratio_i, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
+    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_fe_sqrt_ratio_i, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
     });
 }
 
 // ---- Scalar
-int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, a, b, o, n, 40); }
-int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, a, b, o, n, 40); }
-int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, a, b, o, n, 40); }
-int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40); }
-int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40); }
+int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, zc::k_sc_add_plain, a, b, o, n, 40); }
+int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, zc::k_sc_sub_plain, a, b, o, n, 40); }
+int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, zc::k_sc_mul_plain, a, b, o, n, 40); }
+int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, zc::k_sc_neg_plain, a, o, n, 40); }
+int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, zc::k_sc_square_plain, a, o, n, 40); }
 int zc_sc_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);
     Arg args[3] = {in_arg(in32, 32), out_arg(out, 40), out_arg(ok, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_from_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], 1, cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_from_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], 1, cnt);
     });
 }
 int zc_sc_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n) { return zc_fe_to_bytes(ctx, in, out32, n); }
 
 // ---- EdwardsPoint
-int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, p, q, o, n, 160); }
-int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, p, q, o, n, 160); }
-int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160); }
-int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160); }
+int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, nullptr, p, q, o, n, 160); }
+int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, nullptr, p, q, o, n, 160); }
+int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, nullptr, p, o, n, 160); }
+int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, nullptr, p, o, n, 160); }
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {
@@ -403,32 +439,32 @@ int zc_ed_to_affine(zc_ctx* ctx, const uint64_t* p, uint64_t* xy, uint8_t* ok, s
 {
     REQUIRE(p); REQUIRE(xy);
     Arg args[3] = {in_arg(p, 160), out_arg(xy, 80), out_arg(ok, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
     });
 }
 int zc_ed_eq(zc_ctx* ctx, const uint64_t* p, const uint64_t* q, uint8_t* eq, size_t n)
 {
     REQUIRE(p); REQUIRE(q); REQUIRE(eq);
     Arg args[3] = {in_arg(p, 160), in_arg(q, 160), out_arg(eq, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ed_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
     });
 }
 int zc_ed_compress(zc_ctx* ctx, const uint64_t* p, uint8_t* out32, uint8_t* ok, size_t n)
 {
     REQUIRE(p); REQUIRE(out32);
     Arg args[3] = {in_arg(p, 160), out_arg(out32, 32), out_arg(ok, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ed_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (uint8_t*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], (uint8_t*)d[2], cnt);
     });
 }
 int zc_ed_decompress(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);
     Arg args[3] = {in_arg(in32, 32), out_arg(out, 160), out_arg(ok, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ed_decompress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_decompress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
     });
 }
 
@@ -437,32 +473,33 @@ int zc_ris_compress(zc_ctx* ctx, const uint64_t* p, uint8_t* out32, size_t n)
 {
     REQUIRE(p); REQUIRE(out32);
     Arg args[2] = {in_arg(p, 160), out_arg(out32, 32)};
-    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ris_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (uint8_t*)d[1], cnt);
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ris_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
     });
 }
 int zc_ris_decompress(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);
     Arg args[3] = {in_arg(in32, 32), out_arg(out, 160), out_arg(ok, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ris_decompress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ris_decompress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
     });
 }
 int zc_ris_eq(zc_ctx* ctx, const uint64_t* p, const uint64_t* q, uint8_t* eq, size_t n)
 {
     REQUIRE(p); REQUIRE(q); REQUIRE(eq);
     Arg args[3] = {in_arg(p, 160), in_arg(q, 160), out_arg(eq, 1)};
-    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ris_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ris_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
     });
 }
 int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, uint8_t* out32, uint8_t* ok, size_t n)
 {
     REQUIRE(in32); REQUIRE(k); REQUIRE(out32);
     Arg args[4] = {in_arg(in32, 32), in_arg(k, 40), out_arg(out32, 32), out_arg(ok, 1)};
-    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, hipStream_t s) {
-        hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, s, (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], cnt);
+    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
+        const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
+        hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
     });
 }
 
@@ -521,7 +558,8 @@ int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t 
         if (rc) return rc;
         rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], ((cnt + 1) / 2) * 160 + 64);
         if (rc) return rc;
-        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ds->s(), dP, dK, (size_t)5, (u64*)ds->tmp[0], cnt);
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ds->s(), dP, dK, (size_t)5, (u64*)ds->tmp[0],
+                           balance_index(*ds, dK, cnt), cnt);
         HIP_TRY(hipGetLastError());
         used.push_back(ds);
     }

@@ -141,3 +141,7 @@ void emul_ris_decompress(const u64* in32, u64* out, uint8_t* ok, size_t n)
 void emul_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 { for (size_t i = 0; i < n; i++) eq[i] = ris_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)); }
 }
+extern "C" void emul_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
+{
+    for (size_t lo = 0; lo < n; lo += (size_t)c) fe_invert_chunk(a, out, ok, n, lo, c);
+}

@@ -61,6 +61,14 @@ def test_emul_invert_sqrt_ratio(emul, oracle):
     emul.emul_fe_invert(p(a), p(out), p(ok), C.c_size_t(len(a)))
     want, wok = oracle.fe_invert(a)
     assert np.array_equal(ok, wok) and np.array_equal(out, want)
+    for c in (2, 7, 64):                                      # chunked Montgomery-trick inversion
+        a2 = a.copy()
+        a2[3] = 0
+        a2[-1] = 0
+        out2, ok2 = np.empty_like(a2), np.empty(len(a2), dtype=np.uint8)
+        emul.emul_fe_invert_chunked(p(a2), p(out2), p(ok2), C.c_size_t(len(a2)), c)
+        want2, wok2 = oracle.fe_invert(a2)
+        assert np.array_equal(ok2, wok2) and np.array_equal(out2, want2), c
     u = V.limbs_array(V.rand_fe(120, V.SEED + 4))
     v = V.limbs_array(list(reversed(V.rand_fe(120, V.SEED + 5))))
     sq = np.empty(len(u), dtype=np.uint8)

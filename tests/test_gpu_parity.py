@@ -136,6 +136,17 @@ def test_fe_invert_bulk(eng, oracle):
     assert ok.all() and (prod[:, 0] == 1).all() and not prod[:, 1:].any()
 
 
+def test_fe_invert_chunked_exact(eng, oracle):
+    """Batch sizes that take the Montgomery-trick kernel (chunks of 2 and 4 per lane) vs the
+    oracle's Savas-Koc inverse, with zeros inside and at the ragged end."""
+    for n in ((1 << 18) + 5, (1 << 19) + 1):
+        a = V.rand_fe_np(n, V.SEED + 28)
+        a[[0, 1, 77, n - 1]] = 0
+        out, ok = eng.fe_invert(a)
+        want, wok = oracle.fe_invert(a)
+        assert eq(ok, wok) and eq(out, want) and ok.sum() == n - 4
+
+
 def test_sqrt_ratio_bulk(eng, oracle):
     n = 1500
     u, v = V.rand_fe_np(n, V.SEED + 24), V.rand_fe_np(n, V.SEED + 25)
@@ -303,6 +314,16 @@ def test_device_resident_buffers(eng, oracle):
         prod = eng.fe_mul(da, db)
         torch.cuda.synchronize()
         assert eq(prod.cpu().numpy().view(np.uint64), oracle.fe_mul(a, b))
+        # 8-byte-aligned (not 16) device views take the non-staged kernels
+        prod2 = eng.fe_mul(da[1:], db[1:])
+        sq2 = eng.fe_square(da[1:])
+        inv_in = torch.from_numpy(V.rand_fe_np(1 << 18, V.SEED + 94).view(np.int64)).cuda()
+        inv, okm = eng.fe_invert(inv_in)                          # chunked inversion on device buffers
+        torch.cuda.synchronize()
+        assert eq(prod2.cpu().numpy().view(np.uint64), oracle.fe_mul(a[1:], b[1:]))
+        assert eq(sq2.cpu().numpy().view(np.uint64), oracle.fe_square(a[1:]))
+        hinv = inv_in.cpu().numpy().view(np.uint64)
+        assert eq(inv.cpu().numpy().view(np.uint64)[:4096], oracle.fe_invert(hinv[:4096])[0]) and okm.cpu().numpy().all()
         with pytest.raises(Exception):
             eng.fe_mul(da, b)                                     # host/device mix is refused
     finally:
