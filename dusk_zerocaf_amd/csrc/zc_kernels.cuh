@@ -53,29 +53,38 @@ ZC_DI void add52(u64 (&r)[5], const u64 (&a)[5], const u64 (&b)[5], const u64 (&
 // record is strided in memory, so the block's 256 records (10 KB, contiguous) are moved with
 // coalesced 16-byte loads/stores through LDS and each lane reads/writes its own record there
 // with five ds_read_b64 / ds_write_b64 (stride 40 B = 10 banks: conflict-free in both 32-lane
-// halves).  Requires 16-byte aligned array bases (checked by the host; plain fallback kernel
-// with per-lane global accesses otherwise).
+// halves).  Requires 16-byte aligned array bases (checked by the host, which otherwise uses the
+// per-lane kernel).
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
+template <bool NT>
 ZC_DI void coop_load40(u64* __restrict__ lds, const u64* __restrict__ g, int cnt)
 {
     const int nvec = (cnt * 5) >> 1;                       // 16-byte vectors
     const u64x2* gv = reinterpret_cast<const u64x2*>(g);
     u64x2* lv = reinterpret_cast<u64x2*>(lds);
-    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) lv[v] = __builtin_nontemporal_load(gv + v);
+    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) lv[v] = NT ? __builtin_nontemporal_load(gv + v) : gv[v];
     if ((cnt & 1) && threadIdx.x == 0) lds[cnt * 5 - 1] = g[cnt * 5 - 1];
 }
+template <bool NT>
 ZC_DI void coop_store40(u64* __restrict__ g, const u64* __restrict__ lds, int cnt)
 {
     const int nvec = (cnt * 5) >> 1;
     u64x2* gv = reinterpret_cast<u64x2*>(g);
     const u64x2* lv = reinterpret_cast<const u64x2*>(lds);
-    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) __builtin_nontemporal_store(lv[v], gv + v);
+    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) {
+        if (NT) __builtin_nontemporal_store(lv[v], gv + v);
+        else gv[v] = lv[v];
+    }
     if ((cnt & 1) && threadIdx.x == 0) g[cnt * 5 - 1] = lds[cnt * 5 - 1];
 }
 
 // Op::apply(r, x, y): five-limb radix-2^52 in/out.  NIN = number of input arrays (1 or 2).
-template <class Op, int NIN, bool STAGED>
+// STAGED: 0 = per-lane global accesses, 2 = LDS-staged with non-temporal accesses.  Measured on
+// MI355X (tools/bench_ops.py, 2^24..2^26 elements): staging lifts the compute-free two-input
+// ops (add/sub) from 5.1 to 6.0 TB/s; mul/square (two Montgomery passes per element) and every
+// cache-resident size are as fast or faster with per-lane accesses, so the host picks per op.
+template <class Op, int NIN, int STAGED>
 ZC_DI void elementwise_body(const u64* a, const u64* b, u64* out, size_t n)
 {
     if (STAGED) {
@@ -83,8 +92,8 @@ ZC_DI void elementwise_body(const u64* a, const u64* b, u64* out, size_t n)
         __shared__ __attribute__((aligned(16))) u64 sb[(NIN == 2 ? ZC_BLOCK : 1) * 5];
         const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
         const int cnt = (int)((n - base < (size_t)ZC_BLOCK) ? (n - base) : (size_t)ZC_BLOCK);
-        coop_load40(sa, a + 5 * base, cnt);
-        if (NIN == 2) coop_load40(sb, b + 5 * base, cnt);
+        coop_load40<STAGED == 2>(sa, a + 5 * base, cnt);
+        if (NIN == 2) coop_load40<STAGED == 2>(sb, b + 5 * base, cnt);
         __syncthreads();
         const int t = threadIdx.x;
         if (t < cnt) {
@@ -99,7 +108,7 @@ ZC_DI void elementwise_body(const u64* a, const u64* b, u64* out, size_t n)
             for (int j = 0; j < 5; j++) sa[t * 5 + j] = r[j];   // own slot only
         }
         __syncthreads();
-        coop_store40(out + 5 * base, sa, cnt);
+        coop_store40<STAGED == 2>(out + 5 * base, sa, cnt);
     } else {
         const size_t i = gid();
         if (i >= n) return;
@@ -148,11 +157,11 @@ template <class F> struct OpSqr {
 };
 
 #define ZC_ELEMENTWISE2(name, OP)                                                                       \
-    ZC_KERNEL void name(const u64* a, const u64* b, u64* out, size_t n) { elementwise_body<OP, 2, true>(a, b, out, n); }   \
-    ZC_KERNEL void name##_plain(const u64* a, const u64* b, u64* out, size_t n) { elementwise_body<OP, 2, false>(a, b, out, n); }
+    ZC_KERNEL void name##_stream(const u64* a, const u64* b, u64* out, size_t n) { elementwise_body<OP, 2, 2>(a, b, out, n); } \
+    ZC_KERNEL void name(const u64* a, const u64* b, u64* out, size_t n) { elementwise_body<OP, 2, 0>(a, b, out, n); }
 #define ZC_ELEMENTWISE1(name, OP)                                                                       \
-    ZC_KERNEL void name(const u64* a, u64* out, size_t n) { elementwise_body<OP, 1, true>(a, nullptr, out, n); }            \
-    ZC_KERNEL void name##_plain(const u64* a, u64* out, size_t n) { elementwise_body<OP, 1, false>(a, nullptr, out, n); }
+    ZC_KERNEL void name##_stream(const u64* a, u64* out, size_t n) { elementwise_body<OP, 1, 2>(a, nullptr, out, n); }      \
+    ZC_KERNEL void name(const u64* a, u64* out, size_t n) { elementwise_body<OP, 1, 0>(a, nullptr, out, n); }
 
 ZC_ELEMENTWISE2(k_fe_add, OpAdd<ModP>)
 ZC_ELEMENTWISE2(k_fe_sub, OpSub<ModP>)

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -191,24 +192,26 @@ typedef void (*kun_t)(const u64*, u64*, size_t);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// `k` moves records through LDS with 16-byte accesses and needs 16-byte aligned bases;
-// `k_plain` is the per-lane variant for arbitrarily (8-byte) aligned device pointers.
-int binop(zc_ctx* ctx, kbin_t k, kbin_t k_plain, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
+// Streams larger than this (bytes over all arrays of the call) use the LDS-staged kernel
+// `k_stream` when one is given: it wins only for the compute-free two-input ops beyond the
+// 256 MB Infinity Cache (zc_kernels.cuh, "LDS-staged element I/O").
+constexpr size_t STREAM_BYTES = (size_t)256 << 20;
+
+int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
 {
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     Arg args[3] = {in_arg(a, elt), in_arg(b, elt), out_arg(out, elt)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        kbin_t kk = (k_plain && !(aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]))) ? k_plain : k;
-        hipLaunchKernelGGL(kk, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
+        const bool stream = k_stream && cnt * elt * 3 > STREAM_BYTES && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
+        hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
     });
 }
-int unop(zc_ctx* ctx, kun_t k, kun_t k_plain, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
+int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
 {
     REQUIRE(a); REQUIRE(out);
     Arg args[2] = {in_arg(a, elt), out_arg(out, elt)};
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
-        kun_t kk = (k_plain && !(aligned16(d[0]) && aligned16(d[1]))) ? k_plain : k;
-        hipLaunchKernelGGL(kk, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
+        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
 }
 
@@ -330,11 +333,11 @@ int zc_ctx_synchronize(zc_ctx* ctx)
 }
 
 // ---- FieldElement
-int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, zc::k_fe_add_plain, a, b, o, n, 40); }
-int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, zc::k_fe_sub_plain, a, b, o, n, 40); }
-int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, zc::k_fe_mul_plain, a, b, o, n, 40); }
-int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, zc::k_fe_neg_plain, a, o, n, 40); }
-int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, zc::k_fe_square_plain, a, o, n, 40); }
+int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, zc::k_fe_add_stream, a, b, o, n, 40); }
+int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, zc::k_fe_sub_stream, a, b, o, n, 40); }
+int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, nullptr, a, b, o, n, 40); }
+int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
+int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40); }
 
 int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n)
 {
@@ -378,11 +381,11 @@ int zc_fe_sqrt_ratio_i(zc_ctx* ctx, const uint64_t* u, const uint64_t* v, uint64
 }
 
 // ---- Scalar
-int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, zc::k_sc_add_plain, a, b, o, n, 40); }
-int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, zc::k_sc_sub_plain, a, b, o, n, 40); }
-int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, zc::k_sc_mul_plain, a, b, o, n, 40); }
-int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, zc::k_sc_neg_plain, a, o, n, 40); }
-int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, zc::k_sc_square_plain, a, o, n, 40); }
+int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, zc::k_sc_add_stream, a, b, o, n, 40); }
+int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, zc::k_sc_sub_stream, a, b, o, n, 40); }
+int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, nullptr, a, b, o, n, 40); }
+int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40); }
+int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40); }
 int zc_sc_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);
@@ -396,8 +399,8 @@ int zc_sc_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n) { 
 // ---- EdwardsPoint
 int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, nullptr, p, q, o, n, 160); }
 int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, nullptr, p, q, o, n, 160); }
-int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, nullptr, p, o, n, 160); }
-int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, nullptr, p, o, n, 160); }
+int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160); }
+int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160); }
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {

@@ -121,6 +121,16 @@ def test_fe_mul_full_size_2_20(eng, oracle):
     assert eq(eng.fe_square(a), oracle.fe_square(a))
 
 
+def test_streaming_add_sub_2_22(eng, oracle):
+    """Above the Infinity-Cache size the two-input add/sub take the LDS-staged streaming kernels
+    (ragged tail: odd element count)."""
+    n = (1 << 22) + 3
+    for mod, add, sub, oadd, osub in ((pm.P, eng.fe_add, eng.fe_sub, oracle.fe_add, oracle.fe_sub),
+                                      (pm.L, eng.sc_add, eng.sc_sub, oracle.sc_add, oracle.sc_sub)):
+        a, b = V.rand_fe_np(n, V.SEED + 12, mod), V.rand_fe_np(n, V.SEED + 13, mod)
+        assert eq(add(a, b), oadd(a, b)) and eq(sub(a, b), osub(a, b))
+
+
 def test_fe_invert_bulk(eng, oracle):
     n = (1 << 14) + 3
     a = V.rand_fe_np(n, V.SEED + 22)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-op device-resident timings (HIP events on the launch stream) for the secondary
+kernels of the path.  Prints one JSON object per (op, n).  GPU only."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import dusk_zerocaf_amd as z  # noqa: E402
+from oracle import pymodel as pm  # noqa: E402
+
+
+def main():
+    ops = sys.argv[1].split(",") if len(sys.argv) > 1 else ["fe_add", "fe_mul", "fe_square", "fe_invert"]
+    sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1 << 20, 1 << 24]
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    eng = z.Engine([0])
+    st = torch.cuda.current_stream()
+    eng.set_stream(st.cuda_stream)
+    rng = np.random.default_rng(1)
+    for n in sizes:
+        def fe():
+            a = rng.integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)
+            a[:, 4] >>= np.uint64(8)
+            return torch.from_numpy(a.view(np.int64)).cuda()
+        a, b = fe(), fe()
+        pts = enc = None
+        for op in ops:
+            if op.startswith(("ed_", "ris_")) and pts is None:
+                base = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (n, 1))
+                pts = eng.ed_scalar_mul(torch.from_numpy(base.view(np.int64)).cuda(), a)
+                enc = eng.ris_compress(pts)
+                edc, _ = eng.ed_compress(pts)
+            bytes_per = {"fe_add": 120, "fe_sub": 120, "fe_mul": 120, "fe_square": 80, "fe_neg": 80, "fe_invert": 80,
+                         "sc_mul": 120, "ed_add": 480, "ed_double": 320, "ed_compress": 192, "ed_decompress": 192,
+                         "ris_compress": 192, "ris_decompress": 192, "ed_to_affine": 240, "fe_sqrt_ratio_i": 120}[op]
+            fn = {"fe_add": lambda: eng.fe_add(a, b), "fe_sub": lambda: eng.fe_sub(a, b), "fe_mul": lambda: eng.fe_mul(a, b),
+                  "fe_square": lambda: eng.fe_square(a), "fe_neg": lambda: eng.fe_neg(a), "fe_invert": lambda: eng.fe_invert(a),
+                  "sc_mul": lambda: eng.sc_mul(a, b), "fe_sqrt_ratio_i": lambda: eng.fe_sqrt_ratio_i(a, b),
+                  "ed_add": lambda: eng.ed_add(pts, pts), "ed_double": lambda: eng.ed_double(pts),
+                  "ed_compress": lambda: eng.ed_compress(pts), "ed_decompress": lambda: eng.ed_decompress(edc),
+                  "ris_compress": lambda: eng.ris_compress(pts), "ris_decompress": lambda: eng.ris_decompress(enc),
+                  "ed_to_affine": lambda: eng.ed_to_affine(pts)}[op]
+            fn()
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            print(json.dumps({"op": op, "n": n, "ms": round(ms, 4), "M_per_s": round(n / ms / 1e3, 1),
+                              "alg_GBps": round(bytes_per * n / ms / 1e6, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
