@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-BYTES_PER_UNIT = {"scalar_mul": 360, "fe_mul": 120, "ristretto": 104}   # SURVEY 8(d) algorithmic bytes
+BYTES_PER_UNIT = {"scalar_mul": 360, "fe_mul": 120, "ristretto": 104, "msm": 200}   # SURVEY 8(d) algorithmic bytes
 # measured on MI355X with tools/ubench (profiles/r01_ubench.txt): independent v_mad_u64_u32
 # chains, all CUs -- wave-instructions x 64 lanes per second
 
@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1 << 20, help="units per GPU per step")
-    ap.add_argument("--workload", default="scalar_mul", choices=["scalar_mul", "fe_mul", "ristretto"])
+    ap.add_argument("--workload", default="scalar_mul", choices=["scalar_mul", "fe_mul", "ristretto", "msm"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="units for the CPU baseline (0 disables)")
     ap.add_argument("--check", type=int, default=256, help="elements re-checked against the oracle after timing")
     args = ap.parse_args()
@@ -154,6 +154,15 @@ def main():
     elif args.workload == "fe_mul":
         step = lambda: eng.fe_mul(data["a"], data["b"])
         out = None
+    elif args.workload == "msm":
+        # BASELINE configs[4] shape: every rank reduces its shard with the bucket method, the
+        # 160-byte partials are all-gathered (RCCL) and folded in rank order
+        from dusk_zerocaf_amd import distributed as D
+        out = None
+        msm_result = []
+
+        def step():
+            msm_result[:] = [D.msm_sharded(data["P"], data["K"], eng.msm, eng.ed_add)]
     else:
         out = torch.empty_like(data["enc"])
         step = lambda: eng.ris_roundtrip_mul(data["enc"], data["K"], out=out)
@@ -192,7 +201,8 @@ def main():
     achieved = unit_bytes * n / kern_avg_s / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "kernel": {"scalar_mul": "k_ed_scalar_mul", "fe_mul": "k_fe_mul", "ristretto": "k_ris_roundtrip_mul"}[args.workload],
+                "kernel": {"scalar_mul": "k_ed_scalar_mul", "fe_mul": "k_fe_mul", "ristretto": "k_ris_roundtrip_mul",
+                           "msm": "k_msm_accumulate (+ rocPRIM radix sort, reduce, fold)"}[args.workload],
                 "kernel_avg_ms": round(kern_avg_s * 1e3, 4), "algorithmic_bytes_per_unit": unit_bytes}
     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
     # WRITE_SIZE, profiles/r01_pmc_summary.md), scaled to this launch's unit count
@@ -242,7 +252,7 @@ def main():
     cpu = None
     sample = args.cpu_sample
     if sample < 0:
-        sample = {"scalar_mul": 1 << 13, "ristretto": 1 << 13, "fe_mul": 1 << 24}[args.workload] * usable_cores()
+        sample = {"scalar_mul": 1 << 13, "ristretto": 1 << 13, "fe_mul": 1 << 24, "msm": 1 << 13}[args.workload] * usable_cores()
     if sample:
         if args.workload == "fe_mul":
             hi = data["host"]
@@ -258,16 +268,19 @@ def main():
 
     line = {
         "metric": "252-bit Edwards variable-base scalar-muls/sec (batched, strict bit-exact mode)"
-        if args.workload == "scalar_mul" else args.workload + " units/sec",
+        if args.workload == "scalar_mul" else
+        ("MSM point-scalar pairs/sec (bucket method per GPU, all-gather + ordered fold across GPUs)" if args.workload == "msm"
+         else args.workload + " units/sec"),
         "value": round(value, 1),
-        "unit": "scalar-muls/s" if args.workload != "fe_mul" else "field-muls/s",
+        "unit": {"fe_mul": "field-muls/s", "msm": "pairs/s"}.get(args.workload, "scalar-muls/s"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32x9 limbs (radix 2^29, 64-bit accumulators)", "data": "synthetic",
         "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random 252-bit scalars (BASELINE configs[2])",
                                 "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
-                                "ristretto": "Ristretto decompress->scalar-mul->compress (BASELINE configs[3] shape)"}[args.workload],
+                                "ristretto": "Ristretto decompress->scalar-mul->compress (BASELINE configs[3] shape)",
+                                "msm": "Pippenger MSM, 249-bit scalars, one shard per GPU (BASELINE configs[4] shape)"}[args.workload],
                    "units_per_gpu_per_step": n, "sharding": "contiguous ranges, no collective",
                    "mode": "strict (reference formula sequence, identical X:Y:Z:T limbs)"},
         "roofline": roofline,

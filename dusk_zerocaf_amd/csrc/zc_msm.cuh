@@ -1,0 +1,90 @@
+// zc_msm.cuh -- bucket-method (Pippenger) multi-scalar multiplication kernels.
+// Not in the reference: sum_i k_i * P_i is specified through the reference's
+// own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU:
+//   1. k_msm_digits   : c-bit window digits -> (key = window << c | digit, value = point index)
+//   2. rocPRIM radix sort of the n*W pairs by key (c + log2 W bits)
+//   3. k_msm_bounds   : [start, end) of every bucket in the sorted list
+//   4. k_msm_accumulate: one lane per bucket adds its points with the unified HWCD add
+//   5. k_msm_segments : running-sum reduction of each window in segments of SEG buckets
+//                       (sum_seg = sum (d - lo + 1) B_d, acc_seg = sum B_d)
+//   6. existing kernels: (lo - 1) * acc_seg via k_ed_scalar_mul, k_ed_add, k_ed_fold_pairs down
+//      to one point per window, 2^(c w) * S_w via k_ed_scalar_mul, final fold.
+#pragma once
+#include "zc_kernels.cuh"
+
+namespace zc {
+
+constexpr int MSM_SEG = 16;   // buckets per reduction segment
+
+// digit w of the 260-bit scalar (5 x 52-bit limbs), c <= 16
+ZC_DI u32 scalar_digit(const u64 (&l)[5], int w, int c)
+{
+    const int bit = w * c;
+    const int idx = bit / 52, sh = bit % 52;
+    if (idx >= 5) return 0;
+    u64 x = (l[idx] & M52) >> sh;
+    if (sh + c > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
+    return (u32)x & ((1u << c) - 1);
+}
+
+ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c, int W)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5];
+    load5(l, k + 5 * i);
+    for (int w = 0; w < W; w++) {
+        keys[(size_t)w * n + i] = ((u32)w << c) | scalar_digit(l, w, c);
+        vals[(size_t)w * n + i] = (u32)i;
+    }
+}
+
+// start[key] / end[key] for every key present in the sorted list (arrays pre-zeroed)
+ZC_KERNEL void k_msm_bounds(const u32* keys, u32* start, u32* end, size_t m)
+{
+    const size_t j = gid();
+    if (j >= m) return;
+    const u32 key = keys[j];
+    if (j == 0 || keys[j - 1] != key) start[key] = (u32)j;
+    if (j + 1 == m || keys[j + 1] != key) end[key] = (u32)(j + 1);
+}
+
+// buckets[b] = sum of the points whose (window, digit) == b; digit 0 contributes nothing
+ZC_KERNEL void k_msm_accumulate(const u64* points, const u32* vals, const u32* start, const u32* end, u64* buckets,
+                                size_t nbuckets, int c)
+{
+    const size_t b = gid();
+    if (b >= nbuckets) return;
+    pt acc = pt_identity();
+    if ((b & ((1u << c) - 1)) != 0) {
+        const u32 lo = start[b], hi = end[b];
+        for (u32 j = lo; j < hi; j++) acc = pt_add(acc, pt_load(points + 20 * (size_t)vals[j]));
+    }
+    pt_store(buckets + 20 * b, acc);
+}
+
+// One lane per segment of MSM_SEG consecutive buckets [lo, lo + SEG) of one window:
+//   acc = sum_d B_d,  sum = sum_d (d - lo + 1) B_d   (running sums from the top bucket down)
+// so that  sum_d d * B_d = sum + (lo - 1) * acc.  Emits sum, acc and the scalar (lo - 1) >= 0.
+ZC_KERNEL void k_msm_segments(const u64* buckets, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c)
+{
+    const size_t s = gid();
+    if (s >= nseg_total) return;
+    const size_t first = s * MSM_SEG;                     // global bucket index of the segment start
+    const u32 lo = (u32)(first & ((1u << c) - 1));        // digit value of the first bucket
+    pt acc = pt_identity(), sum = pt_identity();
+    // the lo == 0 segment stops above bucket 0 (digit 0 carries no weight): its running sum is
+    // already sum_d d * B_d and its scalar is 0
+    const int jmin = (lo == 0) ? 1 : 0;
+    for (int j = MSM_SEG - 1; j >= jmin; j--) {
+        acc = pt_add(acc, pt_load(buckets + 20 * (first + j)));
+        sum = pt_add(sum, acc);
+    }
+    pt_store(seg_sum + 20 * s, sum);
+    pt_store(seg_acc + 20 * s, acc);
+    u64* k = seg_scalar + 5 * s;
+    k[0] = (lo == 0) ? 0 : lo - 1;
+    k[1] = 0; k[2] = 0; k[3] = 0; k[4] = 0;
+}
+
+}  // namespace zc

@@ -14,6 +14,9 @@
 
 #include "../../include/zerocaf_hip.h"
 #include "zc_kernels.cuh"
+#include "zc_msm.cuh"
+
+#include <rocprim/rocprim.hpp>
 
 using zc::u64;
 
@@ -50,6 +53,8 @@ struct DevState {
     size_t tmp_bytes[2] = {};
     void* bal = nullptr;                // lane balancing: 1024 u32 bins + n u32 indices
     size_t bal_bytes = 0;
+    void* msm = nullptr;                // bucket-method workspace (zc_msm)
+    size_t msm_bytes = 0;
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -244,6 +249,125 @@ int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, bool broa
     });
 }
 
+// ---------------------------------------------------------------- MSM device pipeline
+constexpr size_t MSM_BUCKET_MIN_N = 1 << 12;
+
+// pairwise folds until one point is left; returns the buffer holding it
+const u64* fold_all(DevState& D, u64* a, u64* b, size_t cnt)
+{
+    u64* cur = a;
+    u64* nxt = b;
+    while (cnt > 1) {
+        hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for((cnt + 1) / 2)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, nxt, cnt);
+        cnt = (cnt + 1) / 2;
+        std::swap(cur, nxt);
+    }
+    return cur;
+}
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <class T> T* take(size_t count)
+    {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u64** result)
+{
+    if (cnt < MSM_BUCKET_MIN_N) {
+        // small shard: n scalar-muls, then pairwise folds
+        int rc = ensure(&D.tmp[0], &D.tmp_bytes[0], cnt * 160);
+        if (rc) return rc;
+        rc = ensure(&D.tmp[1], &D.tmp_bytes[1], ((cnt + 1) / 2) * 160 + 256);
+        if (rc) return rc;
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, dK, (size_t)5, (u64*)D.tmp[0],
+                           (const zc::u32*)nullptr, cnt);
+        *result = fold_all(D, (u64*)D.tmp[0], (u64*)D.tmp[1], cnt);
+        HIP_TRY(hipGetLastError());
+        return ZC_OK;
+    }
+    // window width: ~16-32 points per bucket, 4 <= c <= 16
+    int c = 0;
+    while (((size_t)1 << (c + 1)) <= cnt) c++;
+    c -= 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    const int W = (260 + c - 1) / c;
+    const size_t m = cnt * (size_t)W;
+    if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
+    const size_t nb = (size_t)W << c;                     // buckets
+    const size_t nseg = nb / zc::MSM_SEG;
+    int keybits = c;
+    while ((1 << (keybits - c)) < W) keybits++;
+
+    size_t sort_tmp = 0;
+    {
+        rocprim::double_buffer<zc::u32> kq(nullptr, nullptr), vq(nullptr, nullptr);
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tmp, kq, vq, m, 0, (unsigned)keybits, D.s()));
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv{pass ? (char*)D.msm : nullptr};
+        zc::u32* keys0 = cv.take<zc::u32>(m);
+        zc::u32* keys1 = cv.take<zc::u32>(m);
+        zc::u32* vals0 = cv.take<zc::u32>(m);
+        zc::u32* vals1 = cv.take<zc::u32>(m);
+        char* tmp = cv.take<char>(sort_tmp);
+        zc::u32* start = cv.take<zc::u32>(nb);
+        zc::u32* end = cv.take<zc::u32>(nb);
+        u64* buckets = cv.take<u64>(nb * 20);
+        u64* seg_sum = cv.take<u64>(nseg * 20);
+        u64* seg_acc = cv.take<u64>(nseg * 20);
+        u64* seg_k = cv.take<u64>(nseg * 5);
+        u64* fold_b = cv.take<u64>((nseg / 2 + 1) * 20);
+        u64* win_k = cv.take<u64>((size_t)W * 5);
+        if (!pass) {
+            int rc = ensure(&D.msm, &D.msm_bytes, cv.off);
+            if (rc) return rc;
+            continue;
+        }
+        hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, keys0, vals0, cnt, c, W);
+        rocprim::double_buffer<zc::u32> kb(keys0, keys1), vb(vals0, vals1);
+        size_t st = sort_tmp;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, st, kb, vb, m, 0, (unsigned)keybits, D.s()));
+        HIP_TRY(hipMemsetAsync(start, 0, nb * sizeof(zc::u32), D.s()));
+        HIP_TRY(hipMemsetAsync(end, 0, nb * sizeof(zc::u32), D.s()));
+        hipLaunchKernelGGL(zc::k_msm_bounds, dim3(grid_for(m)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)kb.current(), start, end, m);
+        hipLaunchKernelGGL(zc::k_msm_accumulate, dim3(grid_for(nb)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, (const zc::u32*)vb.current(),
+                           (const zc::u32*)start, (const zc::u32*)end, buckets, nb, c);
+        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)buckets, seg_sum, seg_acc, seg_k, nseg, c);
+        // seg_acc <- (lo - 1) * seg_acc ; seg_sum <- seg_sum + seg_acc
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
+                           seg_acc, (const zc::u32*)nullptr, nseg);
+        hipLaunchKernelGGL(zc::k_ed_add, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_sum, (const u64*)seg_acc, seg_sum, nseg);
+        // fold every window's nseg/W segment sums (power of two per window: pairs never straddle windows)
+        size_t left = nseg;
+        u64* cur = seg_sum;
+        u64* nxt = fold_b;
+        while (left > (size_t)W) {
+            hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for(left / 2)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, nxt, left);
+            left /= 2;
+            std::swap(cur, nxt);
+        }
+        // S_w <- 2^(c w) * S_w, then fold the W window results
+        std::vector<uint64_t> wk((size_t)W * 5, 0);
+        for (int w = 0; w < W; w++) {
+            const int bit = c * w;
+            wk[(size_t)w * 5 + bit / 52] = 1ull << (bit % 52);
+        }
+        HIP_TRY(hipMemcpyAsync(win_k, wk.data(), wk.size() * 8, hipMemcpyHostToDevice, D.s()));
+        HIP_TRY(hipStreamSynchronize(D.s()));              // wk is a local buffer
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(W)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, (const u64*)win_k, (size_t)5, cur,
+                           (const zc::u32*)nullptr, (size_t)W);
+        *result = fold_all(D, cur, nxt, (size_t)W);
+        HIP_TRY(hipGetLastError());
+    }
+    return ZC_OK;
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -307,6 +431,7 @@ int zc_ctx_destroy(zc_ctx* ctx)
         for (int a = 0; a < 2; a++)
             if (ds.tmp[a]) (void)hipFree(ds.tmp[a]);
         if (ds.bal) (void)hipFree(ds.bal);
+        if (ds.msm) (void)hipFree(ds.msm);
         if (ds.stream) (void)hipStreamDestroy(ds.stream);
     }
     delete ctx;
@@ -506,10 +631,9 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
     });
 }
 
-// ---- MSM: sum_i k_i * P_i.  Round-1 realisation: per-GPU batched scalar-mul into a
-// partial array, log2(n) pairwise folds with the unified add, then the per-device
-// partials are folded in device order on device 0.  (A bucket method replaces the
-// first stage later; the result is compared as a group element.)
+// ---- MSM: sum_i k_i * P_i (not in the reference).  Per GPU: bucket method (zc_msm.cuh) for
+// shards of >= MSM_BUCKET_MIN_N pairs, otherwise batched scalar-mul + pairwise folds.  The
+// per-device partial points are folded in device order on the first device.
 int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out_point)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
@@ -526,10 +650,10 @@ int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t 
     if (rp != rk || (rp == RES_DEVICE && dp != dk)) return fail(ZC_ERR_MIXED_MEM, "points/scalars residency differs");
     std::lock_guard<std::mutex> lock(ctx->mu);
 
-    std::vector<uint64_t> partials;
-    size_t ndev = (rp == RES_DEVICE) ? 1 : ctx->devs.size();
+    const size_t ndev = (rp == RES_DEVICE) ? 1 : ctx->devs.size();
     const size_t per = (n + ndev - 1) / ndev;
     std::vector<DevState*> used;
+    std::vector<const u64*> partial_ptr;
     for (size_t di = 0; di < ndev; di++) {
         const size_t lo = di * per, hi = std::min(n, lo + per);
         if (lo >= hi) break;
@@ -557,31 +681,16 @@ int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t 
             dP = (const u64*)ds->scratch[0];
             dK = (const u64*)ds->scratch[1];
         }
-        int rc = ensure(&ds->tmp[0], &ds->tmp_bytes[0], cnt * 160);
+        const u64* part = nullptr;
+        int rc = msm_on_device(*ds, dP, dK, cnt, &part);
         if (rc) return rc;
-        rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], ((cnt + 1) / 2) * 160 + 64);
-        if (rc) return rc;
-        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ds->s(), dP, dK, (size_t)5, (u64*)ds->tmp[0],
-                           balance_index(*ds, dK, cnt), cnt);
-        HIP_TRY(hipGetLastError());
         used.push_back(ds);
+        partial_ptr.push_back(part);
     }
-    // fold per device (ping-pong between tmp[0] and tmp[1])
-    partials.resize(used.size() * 20);
+    std::vector<uint64_t> partials(used.size() * 20);
     for (size_t ui = 0; ui < used.size(); ui++) {
-        DevState* ds = used[ui];
-        const size_t lo = ui * per, hi = std::min(n, lo + per);
-        size_t cnt = hi - lo;
-        HIP_TRY(hipSetDevice(ds->device));
-        int cur = 0;
-        while (cnt > 1) {
-            hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for((cnt + 1) / 2)), dim3(zc::ZC_BLOCK), 0, ds->s(),
-                               (const u64*)ds->tmp[cur], (u64*)ds->tmp[cur ^ 1], cnt);
-            HIP_TRY(hipGetLastError());
-            cnt = (cnt + 1) / 2;
-            cur ^= 1;
-        }
-        HIP_TRY(hipMemcpyAsync(partials.data() + 20 * ui, ds->tmp[cur], 160, hipMemcpyDeviceToHost, ds->s()));
+        HIP_TRY(hipSetDevice(used[ui]->device));
+        HIP_TRY(hipMemcpyAsync(partials.data() + 20 * ui, partial_ptr[ui], 160, hipMemcpyDeviceToHost, used[ui]->s()));
     }
     for (DevState* ds : used) {
         HIP_TRY(hipSetDevice(ds->device));
@@ -592,16 +701,14 @@ int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t 
     if (cnt > 1) {
         DevState* ds = used[0];
         HIP_TRY(hipSetDevice(ds->device));
+        int rc = ensure(&ds->tmp[0], &ds->tmp_bytes[0], cnt * 160);
+        if (rc) return rc;
+        rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], cnt * 160);
+        if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(ds->tmp[0], partials.data(), cnt * 160, hipMemcpyHostToDevice, ds->s()));
-        int cur = 0;
-        while (cnt > 1) {
-            hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for((cnt + 1) / 2)), dim3(zc::ZC_BLOCK), 0, ds->s(),
-                               (const u64*)ds->tmp[cur], (u64*)ds->tmp[cur ^ 1], cnt);
-            HIP_TRY(hipGetLastError());
-            cnt = (cnt + 1) / 2;
-            cur ^= 1;
-        }
-        HIP_TRY(hipMemcpyAsync(partials.data(), ds->tmp[cur], 160, hipMemcpyDeviceToHost, ds->s()));
+        const u64* res = fold_all(*ds, (u64*)ds->tmp[0], (u64*)ds->tmp[1], cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(partials.data(), res, 160, hipMemcpyDeviceToHost, ds->s()));
         HIP_TRY(hipStreamSynchronize(ds->s()));
     }
     memcpy(out_point, partials.data(), 160);

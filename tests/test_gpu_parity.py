@@ -296,13 +296,40 @@ def test_ristretto_roundtrip_mul(eng, oracle):
 
 
 def test_msm_small(eng, oracle):
-    for n in (1, 2, 3, 64, 257):
+    for n in (1, 2, 3, 64, 257):                                  # scalar-mul + fold path
         P = V.base_multiples(oracle, n, V.SEED + 80 + n)
         K = V.rand_scalars_np(n, V.SEED + 81 + n, bits=249)
         got = eng.msm(P, K)
         want = oracle.msm_naive(P, K)
         assert oracle.ed_eq(got, want)[0] == 1
         assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
+
+
+def _gpu_naive_msm(eng, P, K):
+    """sum_i k_i P_i through separately-tested kernels: batched scalar-mul, then pairwise adds."""
+    q = eng.ed_scalar_mul(P, K)
+    while len(q) > 1:
+        if len(q) & 1:
+            q = np.concatenate([q, np.array([V.IDENT_ROW], dtype=np.uint64)])
+        q = eng.ed_add(q[0::2], q[1::2])
+    return q
+
+
+@pytest.mark.parametrize("n,bits", [(4096, 249), (5000, 252), ((1 << 16) + 11, 249), (1 << 18, 252)])
+def test_msm_bucket_method(eng, oracle, n, bits):
+    """Bucket-method shards (window widths 8..14 here): same group element as the reference-op sum."""
+    small = V.base_multiples(oracle, 1 << 10, V.SEED + 84)
+    P = np.tile(small, ((n >> 10) + 1, 1))[:n].copy()
+    K = V.rand_scalars_np(n, V.SEED + 85 + n, bits=bits)
+    K[0] = 0
+    K[1] = [1, 0, 0, 0, 0]
+    K[2] = [(1 << 52) - 1] * 5                                    # all 260 bits set
+    P[3] = V.IDENT_ROW
+    got = eng.msm(P, K)
+    want = oracle.msm_naive(P, K) if n <= 5000 else _gpu_naive_msm(eng, P, K)
+    assert oracle.ed_eq(got, want)[0] == 1
+    assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
+    assert eq(oracle.ris_compress(got), oracle.ris_compress(want))
 
 
 def test_device_resident_buffers(eng, oracle):
