@@ -4,7 +4,10 @@
 //   1. k_msm_digits   : c-bit window digits -> (key = window << c | digit, value = point index)
 //   2. rocPRIM radix sort of the n*W pairs by key (c + log2 W bits)
 //   3. k_msm_bounds   : [start, end) of every bucket in the sorted list
-//   4. k_msm_accumulate: one lane per bucket adds its points with the unified HWCD add
+//   0. k_msm_prepare  : points -> cached form (Y-X, Y+X, Z, 2dT) in Montgomery radix-2^29 (144 B)
+//   4. k_msm_counts + rocPRIM sort of the bucket ids by population (descending), then
+//      k_msm_accumulate: one lane per bucket, lanes of a wave get equally full buckets; each
+//      point costs one 8-multiplication a = -1 addition against the cached form
 //   5. k_msm_segments : running-sum reduction of each window in segments of SEG buckets
 //                       (sum_seg = sum (d - lo + 1) B_d, acc_seg = sum B_d)
 //   6. existing kernels: (lo - 1) * acc_seg via k_ed_scalar_mul, k_ed_add, k_ed_fold_pairs down
@@ -49,16 +52,100 @@ ZC_KERNEL void k_msm_bounds(const u32* keys, u32* start, u32* end, size_t m)
     if (j + 1 == m || keys[j + 1] != key) end[key] = (u32)(j + 1);
 }
 
-// buckets[b] = sum of the points whose (window, digit) == b; digit 0 contributes nothing
-ZC_KERNEL void k_msm_accumulate(const u64* points, const u32* vals, const u32* start, const u32* end, u64* buckets,
-                                size_t nbuckets, int c)
+// Cached ("projective Niels") form of an input point for the bucket sums: (Y-X, Y+X, Z, 2dT),
+// Montgomery radix 2^29, 4 x 9 u32 = 144 bytes.  MSM results are compared as group elements,
+// so the bucket sums are free to use the cheaper dedicated a = -1 addition (HWCD'08 sec. 3.1,
+// 8 multiplications against a cached operand) instead of the reference's 10-multiplication
+// sequence; the sum is the same group element.
+struct niels {
+    fe ymx, ypx, z, t2d;
+};
+ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const pt p = pt_load(points + 20 * i);
+    const fe two_d = fe_reduce<FP>(fe_add(fe_const<FP>(ModP::D_M), fe_const<FP>(ModP::D_M)));
+    fe ymx = fp_sub(p.Y, p.X);
+    fe ypx = fe_add(p.Y, p.X);
+    fe_carry(ypx);
+    const fe t2d = fp_mul(p.T, two_d);
+    u32* o = cached + 36 * i;
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        o[w] = ymx.v[w];
+        o[9 + w] = ypx.v[w];
+        o[18 + w] = p.Z.v[w];
+        o[27 + w] = t2d.v[w];
+    }
+}
+ZC_DI niels niels_load(const u32* __restrict__ c)
+{
+    niels q;
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        q.ymx.v[w] = c[w];
+        q.ypx.v[w] = c[9 + w];
+        q.z.v[w] = c[18 + w];
+        q.t2d.v[w] = c[27 + w];
+    }
+    return q;
+}
+// p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square)
+ZC_DI pt pt_add_cached(const pt& p, const niels& q)
+{
+    const fe A = fp_mul(fp_sub(p.Y, p.X), q.ymx);
+    const fe B = fp_mul(fe_add(p.Y, p.X), q.ypx);
+    const fe C = fp_mul(p.T, q.t2d);
+    const fe ZZ = fp_mul(p.Z, q.z);
+    fe D = fe_add(ZZ, ZZ);
+    fe_carry(D);
+    const fe E = fp_sub(B, A);
+    const fe F = fp_sub(D, C);
+    const fe G = fe_add(D, C);
+    const fe H = fe_add(B, A);
+    pt r;
+    r.X = fp_mul(E, F);
+    r.Y = fp_mul(G, H);
+    r.Z = fp_mul(F, G);
+    r.T = fp_mul(E, H);
+    return r;
+}
+
+// population of every bucket (0 for digit 0, which carries no weight) and its id
+ZC_KERNEL void k_msm_counts(const u32* start, const u32* end, u32* count, u32* ids, size_t nbuckets, int c)
 {
     const size_t b = gid();
     if (b >= nbuckets) return;
+    count[b] = ((b & ((1u << c) - 1)) != 0) ? end[b] - start[b] : 0;
+    ids[b] = (u32)b;
+}
+
+// buckets[b] = sum of the points whose (window, digit) == b.  `order` lists the bucket ids by
+// descending population so the 64 lanes of a wave run (almost) the same trip count.
+ZC_KERNEL void k_msm_accumulate(const u32* cached, const u32* vals, const u32* start, const u32* end, const u32* order,
+                                u64* buckets, size_t nbuckets, int c)
+{
+    const size_t j = gid();
+    if (j >= nbuckets) return;
+    const size_t b = order[j];
     pt acc = pt_identity();
     if ((b & ((1u << c) - 1)) != 0) {
+        // software pipeline: the (random) 144-byte gather of point e+1 and the index of point
+        // e+2 are in flight while point e is being added
         const u32 lo = start[b], hi = end[b];
-        for (u32 j = lo; j < hi; j++) acc = pt_add(acc, pt_load(points + 20 * (size_t)vals[j]));
+        if (lo < hi) {
+            niels cur = niels_load(cached + 36 * (size_t)vals[lo]);
+            u32 inext = (lo + 1 < hi) ? vals[lo + 1] : 0;
+            for (u32 e = lo; e < hi; e++) {
+                const u32 iload = inext;
+                inext = (e + 2 < hi) ? vals[e + 2] : 0;
+                niels nxt = cur;
+                if (e + 1 < hi) nxt = niels_load(cached + 36 * (size_t)iload);
+                acc = pt_add_cached(acc, cur);
+                cur = nxt;
+            }
+        }
     }
     pt_store(buckets + 20 * b, acc);
 }

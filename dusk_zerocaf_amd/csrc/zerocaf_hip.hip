@@ -308,6 +308,9 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     {
         rocprim::double_buffer<zc::u32> kq(nullptr, nullptr), vq(nullptr, nullptr);
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tmp, kq, vq, m, 0, (unsigned)keybits, D.s()));
+        size_t t2 = 0;
+        HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, t2, kq, vq, nb, 0, 32, D.s()));
+        if (t2 > sort_tmp) sort_tmp = t2;
     }
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
@@ -318,6 +321,11 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         char* tmp = cv.take<char>(sort_tmp);
         zc::u32* start = cv.take<zc::u32>(nb);
         zc::u32* end = cv.take<zc::u32>(nb);
+        zc::u32* bcnt0 = cv.take<zc::u32>(nb);
+        zc::u32* bcnt1 = cv.take<zc::u32>(nb);
+        zc::u32* bid0 = cv.take<zc::u32>(nb);
+        zc::u32* bid1 = cv.take<zc::u32>(nb);
+        zc::u32* cached = cv.take<zc::u32>(cnt * 36);
         u64* buckets = cv.take<u64>(nb * 20);
         u64* seg_sum = cv.take<u64>(nseg * 20);
         u64* seg_acc = cv.take<u64>(nseg * 20);
@@ -336,8 +344,13 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         HIP_TRY(hipMemsetAsync(start, 0, nb * sizeof(zc::u32), D.s()));
         HIP_TRY(hipMemsetAsync(end, 0, nb * sizeof(zc::u32), D.s()));
         hipLaunchKernelGGL(zc::k_msm_bounds, dim3(grid_for(m)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)kb.current(), start, end, m);
-        hipLaunchKernelGGL(zc::k_msm_accumulate, dim3(grid_for(nb)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, (const zc::u32*)vb.current(),
-                           (const zc::u32*)start, (const zc::u32*)end, buckets, nb, c);
+        hipLaunchKernelGGL(zc::k_msm_prepare, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
+        hipLaunchKernelGGL(zc::k_msm_counts, dim3(grid_for(nb)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)start, (const zc::u32*)end, bcnt0, bid0, nb, c);
+        rocprim::double_buffer<zc::u32> cb(bcnt0, bcnt1), ib(bid0, bid1);
+        st = sort_tmp;
+        HIP_TRY(rocprim::radix_sort_pairs_desc(tmp, st, cb, ib, nb, 0, 32, D.s()));
+        hipLaunchKernelGGL(zc::k_msm_accumulate, dim3(grid_for(nb)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)cached, (const zc::u32*)vb.current(),
+                           (const zc::u32*)start, (const zc::u32*)end, (const zc::u32*)ib.current(), buckets, nb, c);
         hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)buckets, seg_sum, seg_acc, seg_k, nseg, c);
         // seg_acc <- (lo - 1) * seg_acc ; seg_sum <- seg_sum + seg_acc
         hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
