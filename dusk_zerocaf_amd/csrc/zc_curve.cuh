@@ -212,6 +212,141 @@ ZC_DI void pt_store(u64* __restrict__ o, const pt& p)
     fe_store_canon<FP>(o + 15, p.T);
 }
 
+// ---------------------------------------------------------------- scalar multiplication
+// Scalar words are read through (sk, stride): word w of this lane is sk[w * stride]
+// (LDS with stride = block size in the kernels, a local array with stride 1 on the host).
+ZC_DI void scalar_to_words(u32* __restrict__ sk, int stride, const u64 (&l)[5], int& nbits)
+{
+    u32 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 32 * k, idx = bit / 52, sh = bit % 52;
+        u64 x = (idx < 5) ? ((l[idx] & M52) >> sh) : 0;
+        if (sh + 32 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
+        w[k] = (u32)x;
+    }
+    w[8] &= 0xFu;                                          // 260 bits in total
+    nbits = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (w[k]) nbits = 32 * k + (32 - __builtin_clz(w[k]));
+        sk[k * stride] = w[k];
+    }
+}
+
+// double_and_add (edwards.rs:102-120), unified-step form: each iteration of the loop below
+// evaluates the HWCD formula once for this lane, either Q + N (pending set bit) or N + N.
+// Under SIMT the lanes of a wave run the loop in lock step, so a wave performs
+// max_lane(bitlen - 1 + popcount) formula evaluations.
+ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int stride, int nbits)
+{
+    pt N = P, Q = pt_identity();
+    int pos = 0;
+    u32 cur = sk[0];
+    bool pend = (cur & 1) != 0;
+    bool active = nbits > 0;
+    while (active) {
+        const pt lhs = pt_select(pend, Q, N);
+        const pt r = pt_add(lhs, N);
+        if (pend) {
+            Q = r;
+            pend = false;
+            active = pos < nbits - 1;
+        } else {
+            N = r;
+            pos++;
+            if ((pos & 31) == 0) cur = sk[(pos >> 5) * stride];
+            pend = ((cur >> (pos & 31)) & 1) != 0;
+        }
+    }
+    return Q;
+}
+
+// Left-to-right variants of the reference, same unified-step machinery with
+// Q = Q + Q or Q = Q + (+-P):
+//   MODE 1  ltr_bin_mul     (edwards.rs:122-134): for i = 248..0 { Q = 2Q; if bit_i: Q += P }
+//   MODE 2  binary_naf_mul  (edwards.rs:136-153): for i = 249..0 { Q = 2Q; +-1 digit: Q +-= P }
+// Doubling the literal identity (0,1,1,0) returns the same limbs, so the leading doublings are
+// skipped exactly; the first addition identity + (+-P) is performed literally.  `pos_bits` /
+// `neg_bits` are bit strings (8 words each): positions where P is added / subtracted.
+ZC_DI pt scalar_mul_ltr(const pt& P, const u32* __restrict__ pos_bits, const u32* __restrict__ neg_bits, int stride, int top)
+{
+    pt Q = pt_identity();
+    pt Pn = P;                                             // -P (edwards.rs:440-455), for NAF digits -1
+    Pn.X = fe_reduce<FP>(fp_neg(P.X));
+    Pn.T = fe_reduce<FP>(fp_neg(P.T));
+    int pos = top;
+    bool active = top >= 0;
+    bool pend = true;
+    bool neg = active ? (((neg_bits[(top >> 5) * stride] >> (top & 31)) & 1) != 0) : false;
+    while (active) {
+        pt rhs = pt_select(neg, Pn, P);
+        rhs = pt_select(pend, rhs, Q);
+        Q = pt_add(Q, rhs);
+        if (pend) {
+            pend = false;
+            active = pos > 0;
+        } else {
+            pos--;
+            const u32 pw = pos_bits[(pos >> 5) * stride], nw = neg_bits[(pos >> 5) * stride];
+            neg = ((nw >> (pos & 31)) & 1) != 0;
+            pend = neg || (((pw >> (pos & 31)) & 1) != 0);
+            active = pend || pos > 0;
+        }
+    }
+    return Q;
+}
+// bit strings for the two left-to-right modes from the 5x52 limbs; returns the top index or -1
+template <int MODE>
+ZC_DI int ltr_digits(u32* __restrict__ pos_bits, u32* __restrict__ neg_bits, int stride, const u64 (&l)[5])
+{
+    u32 w[9];
+    int nb;
+    {
+        u32 tmp[9];
+        scalar_to_words(tmp, 1, l, nb);
+#pragma unroll
+        for (int k = 0; k < 9; k++) w[k] = tmp[k];
+    }
+    u32 pw[8], nw[8];
+    if (MODE == 1) {
+        // scalar.into_bits() works on to_bytes(): 256 bits; the loop reads bits 248..0 only
+#pragma unroll
+        for (int k = 0; k < 8; k++) { pw[k] = w[k]; nw[k] = 0; }
+        pw[7] &= 0x01FFFFFFu;                              // bits 224..248
+    } else {
+        // non-adjacent form (scalar.rs:370-389; canonical k < L): with x = 3k,
+        // +1 digits = (x & ~k) >> 1, -1 digits = (~x & k) >> 1; digits 0..249 are read
+        u32 x[9];
+        u64 carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const u64 dbl = ((u64)w[k] << 1) | (k ? (w[k - 1] >> 31) : 0);
+            const u64 s = (u64)w[k] + (dbl & 0xFFFFFFFFull) + carry;
+            x[k] = (u32)s;
+            carry = s >> 32;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 p0 = x[k] & ~w[k], p1 = x[k + 1] & ~w[k + 1];
+            const u32 n0 = ~x[k] & w[k], n1 = ~x[k + 1] & w[k + 1];
+            pw[k] = (p0 >> 1) | (p1 << 31);
+            nw[k] = (n0 >> 1) | (n1 << 31);
+        }
+        pw[7] &= 0x03FFFFFFu;                              // digits 224..249
+        nw[7] &= 0x03FFFFFFu;
+    }
+    int top = -1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 any = pw[k] | nw[k];
+        if (any) top = 32 * k + (31 - __builtin_clz(any));
+        pos_bits[k * stride] = pw[k];
+        neg_bits[k * stride] = nw[k];
+    }
+    return top;
+}
+
 // ---------------------------------------------------------------- byte codecs
 // 32 little-endian bytes (as four u64 words) -> nine 29-bit limbs, all 256 bits kept
 // (from_bytes keeps bits 208..255 in the top limb: field.rs:563-587)

@@ -308,51 +308,6 @@ ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
 // reference loop does not influence Q and is skipped; the first add is performed
 // literally (identity + N), so (X:Y:Z:T) limbs equal the reference's.
 // Scalar words live in LDS (one 32-bit word per lane per refill).
-ZC_DI void scalar_to_words(u32* __restrict__ sk, int tid, const u64 (&l)[5], int& nbits)
-{
-    u32 w[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int bit = 32 * k, idx = bit / 52, sh = bit % 52;
-        u64 x = (idx < 5) ? ((l[idx] & M52) >> sh) : 0;
-        if (sh + 32 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
-        w[k] = (u32)x;
-    }
-    w[8] &= 0xFu;                                          // 260 bits in total
-    nbits = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        if (w[k]) nbits = 32 * k + (32 - __builtin_clz(w[k]));
-        sk[k * ZC_BLOCK + tid] = w[k];
-    }
-}
-
-ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int tid, int nbits)
-{
-    pt N = P, Q = pt_identity();
-    int pos = 0;
-    u32 cur = sk[tid];
-    bool pend = (cur & 1) != 0;
-    bool active = nbits > 0;
-    while (__any(active)) {
-        if (active) {
-            const pt lhs = pt_select(pend, Q, N);
-            const pt r = pt_add(lhs, N);
-            if (pend) {
-                Q = r;
-                pend = false;
-                active = pos < nbits - 1;
-            } else {
-                N = r;
-                pos++;
-                if ((pos & 31) == 0) cur = sk[(pos >> 5) * ZC_BLOCK + tid];
-                pend = ((cur >> (pos & 31)) & 1) != 0;
-            }
-        }
-    }
-    return Q;
-}
-
 // ---- lane balancing -------------------------------------------------------------------
 // A wave needs max over its 64 lanes of (bitlen - 1 + popcount) unified steps.  For random
 // scalars that maximum is ~6 % above the mean, so the batch is first ordered by that cost with
@@ -448,12 +403,32 @@ ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64*
     u64 l[5];
     load5(l, k + k_stride * ii);
     int nbits;
-    scalar_to_words(sk, tid, l, nbits);
+    scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     if (!valid) nbits = 0;
     const pt P = pt_load(p + 20 * ii);
-    const pt Q = scalar_mul_unified(P, sk, tid, nbits);
+    const pt Q = scalar_mul_unified(P, sk + tid, ZC_BLOCK, nbits);
     if (valid) pt_store(out + 20 * ii, Q);
 }
+
+// ltr_bin_mul (MODE 1) / binary_naf_mul (MODE 2): limbs identical to the reference's variants
+template <int MODE>
+ZC_DI void scalar_mul_ltr_body(const u64* p, const u64* k, u64* out, size_t n)
+{
+    __shared__ u32 sp[8 * ZC_BLOCK];
+    __shared__ u32 sn[8 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    const size_t ii = valid ? i : 0;
+    u64 l[5];
+    load5(l, k + 5 * ii);
+    int top = ltr_digits<MODE>(sp + tid, sn + tid, ZC_BLOCK, l);
+    if (!valid) top = -1;
+    const pt Q = scalar_mul_ltr(pt_load(p + 20 * ii), sp + tid, sn + tid, ZC_BLOCK, top);
+    if (valid) pt_store(out + 20 * i, Q);
+}
+ZC_KERNEL void k_ed_scalar_mul_ltr_bin(const u64* p, const u64* k, u64* out, size_t n) { scalar_mul_ltr_body<1>(p, k, out, n); }
+ZC_KERNEL void k_ed_scalar_mul_naf(const u64* p, const u64* k, u64* out, size_t n) { scalar_mul_ltr_body<2>(p, k, out, n); }
 
 // ------------------------------------------------------------------ affine / eq / Edwards codec
 ZC_KERNEL void k_ed_to_affine(const u64* p, u64* xy, uint8_t* ok, size_t n)
@@ -532,11 +507,11 @@ ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out
     load_words256(w, in + 32 * ii);
     load5(l, k + 5 * ii);
     int nbits;
-    scalar_to_words(sk, tid, l, nbits);
+    scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     pt P;
     const bool dec = ris_decompress(P, w);
     if (!valid || !dec) nbits = 0;
-    const pt Q = scalar_mul_unified(P, sk, tid, nbits);
+    const pt Q = scalar_mul_unified(P, sk + tid, ZC_BLOCK, nbits);
     fe_to_words256(w, ris_compress(Q));
     if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
     if (valid) {

@@ -205,7 +205,8 @@ constexpr size_t STREAM_BYTES = (size_t)256 << 20;
 int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
 {
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
-    Arg args[3] = {in_arg(a, elt), in_arg(b, elt), out_arg(out, elt)};
+    // elt == 0: (point, scalar) -> point
+    Arg args[3] = {in_arg(a, elt ? elt : 160), in_arg(b, elt ? elt : 40), out_arg(out, elt ? elt : 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
         const bool stream = k_stream && cnt * elt * 3 > STREAM_BYTES && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
         hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
@@ -542,8 +543,10 @@ int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {
-    if (flags != ZC_SCALAR_MUL_STRICT) return fail(ZC_ERR_BAD_ARG, "unknown scalar_mul flags");
-    return scalar_mul_impl(ctx, p, k, false, out, n);
+    if (flags == ZC_SCALAR_MUL_STRICT) return scalar_mul_impl(ctx, p, k, false, out, n);
+    if (flags == ZC_SCALAR_MUL_LTR_BIN) return binop(ctx, zc::k_ed_scalar_mul_ltr_bin, nullptr, p, k, out, n, 0);
+    if (flags == ZC_SCALAR_MUL_BINARY_NAF) return binop(ctx, zc::k_ed_scalar_mul_naf, nullptr, p, k, out, n, 0);
+    return fail(ZC_ERR_BAD_ARG, "unknown scalar_mul flags");
 }
 int zc_ed_mul_by_pow_2(zc_ctx* ctx, const uint64_t* p, uint64_t kexp, uint64_t* out, size_t n)
 {

@@ -15,7 +15,9 @@ import numpy as np
 
 from . import _lib
 
-STRICT = 0
+STRICT = 0          # double_and_add (Mul<Scalar>)
+LTR_BIN = 1         # ltr_bin_mul
+BINARY_NAF = 2      # binary_naf_mul
 
 
 def _is_torch(x) -> bool:

@@ -52,7 +52,11 @@ typedef enum zc_status {
     ZC_ERR_MIXED_MEM = -5    /* buffers of one call live on different devices */
 } zc_status;
 
-#define ZC_SCALAR_MUL_STRICT 0u  /* reference formula sequence: (X:Y:Z:T) limbs identical */
+/* zc_ed_scalar_mul flags: which reference algorithm's formula sequence is reproduced.  All
+ * three give (X:Y:Z:T) limbs identical to the named reference function.                    */
+#define ZC_SCALAR_MUL_STRICT 0u      /* double_and_add = Mul<Scalar>, src/edwards.rs:102-120     */
+#define ZC_SCALAR_MUL_LTR_BIN 1u     /* ltr_bin_mul, src/edwards.rs:122-134 (reads bits 248..0)  */
+#define ZC_SCALAR_MUL_BINARY_NAF 2u  /* binary_naf_mul, src/edwards.rs:136-153 (canonical k < L) */
 
 /* ---- context -------------------------------------------------------------- */
 /* devices == NULL / ndev == 0: use the current HIP device.  With ndev > 1, calls on

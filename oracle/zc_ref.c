@@ -1028,6 +1028,17 @@ void zr_ed_neg_batch(const uint64_t *p, uint64_t *out, size_t n)
 { for (size_t i = 0; i < n; i++) { zr_pt r; zr_ed_neg(&r, PT(p, i)); *PTO(out, i) = r; } }
 void zr_ed_scalar_mul_batch(const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n)
 { for (size_t i = 0; i < n; i++) { zr_pt r; zr_ed_scalar_mul(&r, PT(p, i), FE(k, i)); *PTO(out, i) = r; } }
+/* mode 0: double_and_add (E:102-120), 1: ltr_bin_mul (E:122-134), 2: binary_naf_mul (E:136-153) */
+void zr_ed_scalar_mul_mode_batch(const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n, int mode)
+{
+    for (size_t i = 0; i < n; i++) {
+        zr_pt r;
+        if (mode == 1) zr_ed_ltr_bin_mul(&r, PT(p, i), FE(k, i));
+        else if (mode == 2) zr_ed_binary_naf_mul(&r, PT(p, i), FE(k, i));
+        else zr_ed_scalar_mul(&r, PT(p, i), FE(k, i));
+        *PTO(out, i) = r;
+    }
+}
 void zr_ed_mul_by_pow_2_batch(const uint64_t *p, uint64_t kexp, uint64_t *out, size_t n)
 { for (size_t i = 0; i < n; i++) { zr_pt r; zr_ed_mul_by_pow_2(&r, PT(p, i), kexp); *PTO(out, i) = r; } }
 void zr_ed_to_affine_batch(const uint64_t *p, uint64_t *xy, uint8_t *ok, size_t n)

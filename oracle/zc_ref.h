@@ -130,6 +130,7 @@ void zr_ed_sub_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t
 void zr_ed_double_batch(const uint64_t *p, uint64_t *out, size_t n);
 void zr_ed_neg_batch(const uint64_t *p, uint64_t *out, size_t n);
 void zr_ed_scalar_mul_batch(const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n);
+void zr_ed_scalar_mul_mode_batch(const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n, int mode);
 void zr_ed_mul_by_pow_2_batch(const uint64_t *p, uint64_t kexp, uint64_t *out, size_t n);
 void zr_ed_to_affine_batch(const uint64_t *p, uint64_t *xy, uint8_t *ok, size_t n);
 void zr_ed_eq_batch(const uint64_t *p, const uint64_t *q, uint8_t *eq, size_t n);

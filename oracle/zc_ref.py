@@ -138,6 +138,14 @@ def ed_scalar_mul(p, k):
     return out
 
 
+def ed_scalar_mul_mode(p, k, mode):
+    """mode 0 double_and_add, 1 ltr_bin_mul, 2 binary_naf_mul."""
+    p, k = _u64(p, 20), _u64(k, 5)
+    out = np.empty_like(p)
+    lib().zr_ed_scalar_mul_mode_batch(_p(p), _p(k), _p(out), C.c_size_t(p.shape[0]), C.c_int(mode))
+    return out
+
+
 def ed_mul_by_pow_2(p, kexp):
     p = _u64(p, 20)
     out = np.empty_like(p)

@@ -12,29 +12,17 @@ using namespace zc;
 
 static pt scalar_mul_seq(const pt& P, const u64 (&l)[5])
 {
-    // same op sequence as scalar_mul_unified (zc_kernels.cuh), one lane
     u32 w[9];
-    for (int k = 0; k < 9; k++) {
-        const int bit = 32 * k, idx = bit / 52, sh = bit % 52;
-        u64 x = (idx < 5) ? ((l[idx] & M52) >> sh) : 0;
-        if (sh + 32 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
-        w[k] = (u32)x;
-    }
-    w[8] &= 0xFu;
-    int nbits = 0;
-    for (int k = 0; k < 9; k++)
-        if (w[k]) nbits = 32 * k + (32 - __builtin_clz(w[k]));
-    pt N = P, Q = pt_identity();
-    int pos = 0;
-    bool pend = (w[0] & 1) != 0;
-    bool active = nbits > 0;
-    while (active) {
-        const pt lhs = pt_select(pend, Q, N);
-        const pt r = pt_add(lhs, N);
-        if (pend) { Q = r; pend = false; active = pos < nbits - 1; }
-        else { N = r; pos++; pend = ((w[pos >> 5] >> (pos & 31)) & 1) != 0; }
-    }
-    return Q;
+    int nbits;
+    scalar_to_words(w, 1, l, nbits);
+    return scalar_mul_unified(P, w, 1, nbits);        // the very function the kernels run per lane
+}
+template <int MODE>
+static pt scalar_mul_ltr_seq(const pt& P, const u64 (&l)[5])
+{
+    u32 pb[8], nb[8];
+    const int top = ltr_digits<MODE>(pb, nb, 1, l);
+    return scalar_mul_ltr(P, pb, nb, 1, top);
 }
 
 template <class F>
@@ -144,4 +132,13 @@ void emul_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 extern "C" void emul_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
 {
     for (size_t lo = 0; lo < n; lo += (size_t)c) fe_invert_chunk(a, out, ok, n, lo, c);
+}
+extern "C" void emul_ed_scalar_mul_mode(const u64* p, const u64* k, u64* out, size_t n, int mode)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 l[5];
+        ld5(l, k + 5 * i);
+        const pt P = pt_load(p + 20 * i);
+        pt_store(out + 20 * i, mode == 1 ? scalar_mul_ltr_seq<1>(P, l) : scalar_mul_ltr_seq<2>(P, l));
+    }
 }

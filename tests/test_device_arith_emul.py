@@ -99,6 +99,18 @@ def test_emul_point_ops(emul, oracle):
     K[6] = pm.limbs(8)
     emul.emul_ed_scalar_mul(p(P), p(K), p(out), C.c_size_t(n))
     assert np.array_equal(out, oracle.ed_scalar_mul(P, K))   # strict (X:Y:Z:T) limbs
+    Kc = V.rand_scalars_np(n, V.SEED + 14, bits=249)            # canonical scalars (< 2^249 < L)
+    Kc[0] = 0
+    Kc[1] = [1, 0, 0, 0, 0]
+    Kc[2] = pm.limbs(pm.L - 1)
+    Kc[3] = pm.limbs(2**249 - 1)
+    Kc[4] = pm.limbs(2**248)
+    Kc[5] = pm.limbs(3)
+    Kc[6] = pm.limbs(2**249)
+    for mode in (1, 2):                                         # ltr_bin_mul / binary_naf_mul limbs
+        emul.emul_ed_scalar_mul_mode(p(P), p(Kc), p(out), C.c_size_t(n), mode)
+        assert np.array_equal(out, oracle.ed_scalar_mul_mode(P, Kc, mode)), mode
+    emul.emul_ed_scalar_mul(p(P), p(K), p(out), C.c_size_t(n))
     xy, ok = np.empty((n, 10), dtype=np.uint64), np.empty(n, dtype=np.uint8)
     emul.emul_ed_to_affine(p(out), p(xy), p(ok), C.c_size_t(n))
     wxy, wok = oracle.ed_to_affine(out)

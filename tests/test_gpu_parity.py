@@ -223,6 +223,26 @@ def test_scalar_mul_strict_limbs(eng, oracle, n, bits):
     assert eq(eng.ed_scalar_mul(P, K), oracle.ed_scalar_mul(P, K))
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_scalar_mul_reference_variants(eng, oracle, mode):
+    """ltr_bin_mul / binary_naf_mul (edwards.rs:122-153): limbs identical to the reference's
+    variant, and the same group element as double_and_add (reference tests left_to_right_bin_mul,
+    naf_bin_mul)."""
+    n = 1500
+    P = V.base_multiples(oracle, n, V.SEED + 45)
+    K = V.rand_scalars_np(n, V.SEED + 46 + mode, bits=249 if mode == 2 else 248)
+    K[0] = 0
+    K[1] = [1, 0, 0, 0, 0]
+    K[2] = pm.limbs(2**215)
+    K[3] = pm.limbs(2**7)
+    if mode == 2:
+        K[4] = pm.limbs(pm.L - 1)
+        K[5] = pm.limbs(2**249 - 1)
+    got = eng.ed_scalar_mul(P, K, flags=mode)
+    assert eq(got, oracle.ed_scalar_mul_mode(P, K, mode))
+    assert eng.ed_eq(got, eng.ed_scalar_mul(P, K)).all()
+
+
 def test_scalar_mul_full_size_properties(eng, oracle):
     """config 3 at 2^20: linearity (k1+k2)P == k1P + k2P on every element, plus an
     oracle-checked stride sample of exact limbs."""
