@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="units per GPU per step")
+    ap.add_argument("--units", "--n", dest="n", type=int, default=1 << 20, help="units per GPU per step")
     ap.add_argument("--workload", default="scalar_mul", choices=["scalar_mul", "fe_mul", "ristretto", "msm"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="units for the CPU baseline (0 disables)")
     ap.add_argument("--check", type=int, default=256, help="elements re-checked against the oracle after timing")
