@@ -49,6 +49,13 @@ SIGNATURES = {
     "zc_ris_decompress": [_u8p, _u64p, _u8p, _n],
     "zc_ris_eq": [_u64p, _u64p, _u8p, _n],
     "zc_ris_roundtrip_mul": [_u8p, _u64p, _u8p, _u8p, _n],
+    "zc_ed_is_valid": [_u64p, _u8p, _n],
+    "zc_ris_is_valid": [_u64p, _u8p, _n],
+    "zc_ris_elligator": [_u64p, _u64p, _n],
+    "zc_ris_from_uniform_bytes": [_u8p, _u64p, _n],
+    "zc_proj_add": [_u64p, _u64p, _u64p, _n],
+    "zc_proj_double": [_u64p, _u64p, _n],
+    "zc_proj_to_extended": [_u64p, _u64p, _n],
     "zc_msm": [_u64p, _u64p, _n, _u64p],
 }
 CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_set_stream", "zc_ctx_synchronize",

@@ -507,4 +507,79 @@ ZC_DI bool ed_decompress(pt& out, const u64 (&win)[4])
     return have && !fp_is_zero(den);
 }
 
+// ---------------------------------------------------------------- "next" rows
+// Ristretto-flavoured Elligator map (ristretto.rs:430-471).  r0 is used as given (the
+// reference's own KAT feeds a non-canonical 253-bit value), everything is value arithmetic.
+ZC_DI pt ris_elligator(const fe& r0)
+{
+    const fe one = fe_one_m<FP>();
+    const fe d = fe_const<FP>(ModP::D_M);
+    const fe minus_one = fe_const<FP>(ModP::MINUS_ONE_M);
+    const fe r = fp_mul(fe_const<FP>(ModP::SQRT_M1_M), fp_sqr(r0));
+    const fe Ns = fp_mul(fe_add(r, one), fe_const<FP>(ModP::ONE_MINUS_D_SQ_M));
+    const fe D = fp_mul(fp_sub(minus_one, fp_mul(d, r)), fe_add(r, d));
+    fe s;
+    const bool is_sq = fp_sqrt_ratio_i(s, Ns, D);
+    fe sp = fp_mul(s, r0);
+    sp = fe_select(fp_is_positive(sp), fe_reduce<FP>(fp_neg(sp)), sp);      // s' = -|s * r0|
+    s = fe_select(is_sq, s, sp);
+    const fe c = fe_select(is_sq, minus_one, r);
+    const fe Nt = fp_sub(fp_mul(fp_mul(c, fp_sub(r, one)), fe_const<FP>(ModP::D_MINUS_ONE_SQ_M)), D);
+    const fe ssq = fp_sqr(s);
+    const fe W0 = fp_mul(fe_add(s, s), D);
+    const fe W1 = fp_mul(Nt, fe_const<FP>(ModP::SQRT_AD_MINUS_ONE_M));
+    const fe W2 = fp_sub(one, ssq);
+    const fe W3 = fe_add(one, ssq);
+    pt o;
+    o.X = fp_mul(W0, W3);
+    o.Y = fp_mul(W2, W1);
+    o.Z = fp_mul(W1, W3);
+    o.T = fp_mul(W0, W2);
+    return o;
+}
+// curve equation in projective form (edwards.rs:733-748): (a X^2 + Y^2) Z^2 == Z^4 + d X^2 Y^2
+ZC_DI bool ed_is_valid(const pt& p)
+{
+    const fe xs = fp_sqr(p.X), ys = fp_sqr(p.Y), zs = fp_sqr(p.Z);
+    const fe left = fp_mul(fp_sub(ys, xs), zs);                              // a = -1
+    const fe right = fe_add(fp_sqr(zs), fp_mul(fp_mul(fe_const<FP>(ModP::D_M), xs), ys));
+    return fe_is_zero_canon(fp_canon(fp_sub(right, left)));
+}
+// ProjectivePoint (X:Y:Z) add / double (edwards.rs:809-834, :915-942)
+struct ppt {
+    fe X, Y, Z;
+};
+ZC_DI ppt proj_add(const ppt& p, const ppt& q)
+{
+    const fe A = fp_mul(p.Z, q.Z);
+    const fe B = fp_sqr(A);
+    const fe C = fp_mul(p.X, q.X);
+    const fe D = fp_mul(p.Y, q.Y);
+    const fe E = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), C), D);
+    const fe F = fp_sub(B, E);
+    const fe G = fe_add(B, E);
+    fe t = fp_mul(fe_add(p.X, p.Y), fe_add(q.X, q.Y));
+    t = fp_sub(fp_sub(t, C), D);
+    ppt r;
+    r.X = fp_mul(A, fp_mul(F, t));
+    r.Y = fp_mul(fp_mul(A, G), fe_add(D, C));
+    r.Z = fp_mul(F, G);
+    return r;
+}
+ZC_DI ppt proj_double(const ppt& p)
+{
+    const fe B = fp_sqr(fe_add(p.X, p.Y));
+    const fe C = fp_sqr(p.X);
+    const fe D = fp_sqr(p.Y);
+    const fe F = fp_sub(D, C);                                               // E + D with E = a*C = -C
+    const fe H = fp_sqr(p.Z);
+    const fe J = fp_sub(fp_sub(F, H), H);                                    // F - 2H
+    const fe EmD = fp_sub(fp_neg(C), D);                                     // E - D = -C - D
+    ppt r;
+    r.X = fp_mul(fp_sub(fp_sub(B, C), D), J);
+    r.Y = fp_mul(F, EmD);
+    r.Z = fp_mul(F, J);
+    return r;
+}
+
 }  // namespace zc

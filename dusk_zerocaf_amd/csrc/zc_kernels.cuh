@@ -520,6 +520,87 @@ ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out
     }
 }
 
+// ------------------------------------------------------------------ "next" rows: validity, Elligator, ProjectivePoint
+ZC_KERNEL void k_ed_is_valid(const u64* p, uint8_t* valid, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    valid[i] = ed_is_valid(pt_load(p + 20 * i)) ? 1 : 0;
+}
+// RistrettoPoint::is_valid (ristretto.rs:205-222): (P * L == identity) & on-curve
+ZC_KERNEL void k_ris_is_valid(const u64* p, uint8_t* valid, size_t n)
+{
+    __shared__ u32 sk[9 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool in = i < n;
+    const pt P = pt_load(p + 20 * (in ? i : 0));
+    u64 l[5];
+    fe_to_limbs52(l, fe_const<ModL>(ModL::N));
+    int nbits;
+    scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
+    const pt Q = scalar_mul_unified(P, sk + tid, ZC_BLOCK, in ? nbits : 0);
+    const bool order_l = ed_eq(Q, pt_identity());
+    if (in) valid[i] = (order_l && ed_is_valid(P)) ? 1 : 0;
+}
+ZC_KERNEL void k_ris_elligator(const u64* r0, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    pt_store(out + 20 * i, ris_elligator(fe_load_mont<FP>(r0 + 5 * i)));
+}
+// from_uniform_bytes (ristretto.rs:493-507): two Elligator maps, one addition
+ZC_KERNEL void k_ris_from_uniform_bytes(const uint8_t* in, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 w[4];
+    load_words256(w, in + 64 * i);
+    const pt R1 = ris_elligator(mont_to<FP>(fe_from_words256(w)));
+    load_words256(w, in + 64 * i + 32);
+    const pt R2 = ris_elligator(mont_to<FP>(fe_from_words256(w)));
+    pt_store(out + 20 * i, pt_add(R1, R2));
+}
+ZC_DI ppt ppt_load(const u64* __restrict__ p)
+{
+    ppt r;
+    r.X = fe_load_mont<FP>(p);
+    r.Y = fe_load_mont<FP>(p + 5);
+    r.Z = fe_load_mont<FP>(p + 10);
+    return r;
+}
+ZC_DI void ppt_store(u64* __restrict__ o, const ppt& p)
+{
+    fe_store_canon<FP>(o, p.X);
+    fe_store_canon<FP>(o + 5, p.Y);
+    fe_store_canon<FP>(o + 10, p.Z);
+}
+ZC_KERNEL void k_proj_add(const u64* p, const u64* q, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    ppt_store(out + 15 * i, proj_add(ppt_load(p + 15 * i), ppt_load(q + 15 * i)));
+}
+ZC_KERNEL void k_proj_double(const u64* p, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    ppt_store(out + 15 * i, proj_double(ppt_load(p + 15 * i)));
+}
+// From<ProjectivePoint> for EdwardsPoint (edwards.rs:402-417): (X*Z, Y*Z, Z^2, X*Y)
+ZC_KERNEL void k_proj_to_extended(const u64* p, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const ppt a = ppt_load(p + 15 * i);
+    pt r;
+    r.X = fp_mul(a.X, a.Z);
+    r.Y = fp_mul(a.Y, a.Z);
+    r.Z = fp_sqr(a.Z);
+    r.T = fp_mul(a.X, a.Y);
+    pt_store(out + 20 * i, r);
+}
+
 // ------------------------------------------------------------------ reduction helper for zc_msm
 // out[i] = in[2i] + in[2i+1] (odd tail copied): pairwise fold of a point array
 ZC_KERNEL void k_ed_fold_pairs(const u64* in, u64* out, size_t n_in)

@@ -647,6 +647,50 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
     });
 }
 
+// ---- "next" rows (N3, N4)
+int zc_ed_is_valid(zc_ctx* ctx, const uint64_t* p, uint8_t* valid, size_t n)
+{
+    REQUIRE(p); REQUIRE(valid);
+    Arg args[2] = {in_arg(p, 160), out_arg(valid, 1)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_is_valid, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_ris_is_valid(zc_ctx* ctx, const uint64_t* p, uint8_t* valid, size_t n)
+{
+    REQUIRE(p); REQUIRE(valid);
+    Arg args[2] = {in_arg(p, 160), out_arg(valid, 1)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ris_is_valid, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_ris_elligator(zc_ctx* ctx, const uint64_t* r0, uint64_t* out, size_t n)
+{
+    REQUIRE(r0); REQUIRE(out);
+    Arg args[2] = {in_arg(r0, 40), out_arg(out, 160)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ris_elligator, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
+    });
+}
+int zc_ris_from_uniform_bytes(zc_ctx* ctx, const uint8_t* in64, uint64_t* out, size_t n)
+{
+    REQUIRE(in64); REQUIRE(out);
+    Arg args[2] = {in_arg(in64, 64), out_arg(out, 160)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ris_from_uniform_bytes, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (u64*)d[1], cnt);
+    });
+}
+int zc_proj_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_proj_add, nullptr, p, q, o, n, 120); }
+int zc_proj_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_proj_double, p, o, n, 120); }
+int zc_proj_to_extended(zc_ctx* ctx, const uint64_t* p, uint64_t* out, size_t n)
+{
+    REQUIRE(p); REQUIRE(out);
+    Arg args[2] = {in_arg(p, 120), out_arg(out, 160)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_proj_to_extended, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
+    });
+}
+
 // ---- MSM: sum_i k_i * P_i (not in the reference).  Per GPU: bucket method (zc_msm.cuh) for
 // shards of >= MSM_BUCKET_MIN_N pairs, otherwise batched scalar-mul + pairwise folds.  The
 // per-device partial points are folded in device order on the first device.

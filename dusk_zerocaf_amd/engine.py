@@ -250,6 +250,37 @@ class Engine:
         self._call("zc_ris_roundtrip_mul", pb, pk, po, pko, n)
         return out, ok
 
+    # ------------------------------------------------------------------ next rows (N3, N4)
+    def _flag(self, name, p):
+        p, pp, n = self._prep(p, 20, np.uint64)
+        v, pv = self._alloc(p, n, 0, np.uint8)
+        self._call(name, pp, pv, n)
+        return v
+
+    def ed_is_valid(self, p): return self._flag("zc_ed_is_valid", p)
+    def ris_is_valid(self, p): return self._flag("zc_ris_is_valid", p)
+
+    def ris_elligator(self, r0):
+        r0, pr, n = self._prep(r0, 5, np.uint64)
+        out, po = self._alloc(r0, n, 20, np.uint64)
+        self._call("zc_ris_elligator", pr, po, n)
+        return out
+
+    def ris_from_uniform_bytes(self, b):
+        b, pb, n = self._prep(b, 64, np.uint8)
+        out, po = self._alloc_u64(b, n, 20)
+        self._call("zc_ris_from_uniform_bytes", pb, po, n)
+        return out
+
+    def proj_add(self, p, q): return self._bin("zc_proj_add", p, q, 15)
+    def proj_double(self, p): return self._un("zc_proj_double", p, 15)
+
+    def proj_to_extended(self, p):
+        p, pp, n = self._prep(p, 15, np.uint64)
+        out, po = self._alloc(p, n, 20, np.uint64)
+        self._call("zc_proj_to_extended", pp, po, n)
+        return out
+
     # ------------------------------------------------------------------ MSM (not in the reference)
     def msm(self, points, scalars):
         points, pp, n = self._prep(points, 20, np.uint64)

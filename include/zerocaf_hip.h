@@ -133,6 +133,21 @@ int zc_ris_eq(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint8_t *eq_out
 int zc_ris_roundtrip_mul(zc_ctx *ctx, const uint8_t *in32, const uint64_t *k, uint8_t *out32,
                          uint8_t *ok, size_t n);
 
+/* ---- "next" rows of the scope table ----------------------------------- */
+/* ValidityCheck for EdwardsPoint: src/edwards.rs:393-400, :733-748 (curve equation)        */
+int zc_ed_is_valid(zc_ctx *ctx, const uint64_t *p, uint8_t *valid_out, size_t n);
+/* ValidityCheck for RistrettoPoint: src/ristretto.rs:205-222 (order exactly L, on curve)   */
+int zc_ris_is_valid(zc_ctx *ctx, const uint64_t *p, uint8_t *valid_out, size_t n);
+/* elligator_ristretto_flavor: src/ristretto.rs:430-471 (r0: FieldElement limbs, used as given) */
+int zc_ris_elligator(zc_ctx *ctx, const uint64_t *r0, uint64_t *out, size_t n);
+/* from_uniform_bytes: src/ristretto.rs:493-507 (in64: n x 64 bytes)                         */
+int zc_ris_from_uniform_bytes(zc_ctx *ctx, const uint8_t *in64, uint64_t *out, size_t n);
+/* ProjectivePoint (X|Y|Z = 15 x uint64): Add src/edwards.rs:809-834, Double :915-942,
+ * From<ProjectivePoint> for EdwardsPoint :402-417                                           */
+int zc_proj_add(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
+int zc_proj_double(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+int zc_proj_to_extended(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+
 /* ---- multi-scalar multiplication (not in the reference: sum_i k_i * P_i) -------- */
 /* out_point: one EdwardsPoint (HOST memory), equal to the reference's
  * sum of `&P_i * &k_i` as a group element (compare with ==, i.e. affine/compressed). */

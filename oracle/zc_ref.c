@@ -962,6 +962,85 @@ void zr_ris_elligator(zr_pt *out, const zr_fe *r0)
     zr_fe_mul(&out->T, &W0, &W2);
 }
 
+/* ------------------------------------------------------------------ ProjectivePoint (X:Y:Z) */
+/* E:809-834 (BBJLP'08 projective add, a = -1); p, q, r: 3 field elements X|Y|Z */
+void zr_proj_add(zr_fe r[3], const zr_fe p[3], const zr_fe q[3])
+{
+    zr_fe A, B, C, D, E, F, G, t0, t1, o[3];
+    zr_fe_mul(&A, &p[2], &q[2]);
+    zr_fe_square(&B, &A);
+    zr_fe_mul(&C, &p[0], &q[0]);
+    zr_fe_mul(&D, &p[1], &q[1]);
+    zr_fe_mul(&E, &ZR_EDWARDS_D, &C);
+    zr_fe_mul(&E, &E, &D);
+    zr_fe_sub(&F, &B, &E);
+    zr_fe_add(&G, &B, &E);
+    zr_fe_add(&t0, &p[0], &p[1]);
+    zr_fe_add(&t1, &q[0], &q[1]);
+    zr_fe_mul(&t0, &t0, &t1);
+    zr_fe_sub(&t0, &t0, &C);
+    zr_fe_sub(&t0, &t0, &D);
+    zr_fe_mul(&t0, &F, &t0);
+    zr_fe_mul(&o[0], &A, &t0);
+    zr_fe_mul(&t1, &A, &G);
+    zr_fe_add(&t0, &D, &C);
+    zr_fe_mul(&o[1], &t1, &t0);
+    zr_fe_mul(&o[2], &F, &G);
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+}
+/* E:915-942 (dedicated projective doubling) */
+void zr_proj_double(zr_fe r[3], const zr_fe p[3])
+{
+    const zr_fe two = {{2, 0, 0, 0, 0}};
+    zr_fe B, C, D, E, F, H, J, t0, o[3];
+    zr_fe_add(&t0, &p[0], &p[1]);
+    zr_fe_square(&B, &t0);
+    zr_fe_square(&C, &p[0]);
+    zr_fe_square(&D, &p[1]);
+    zr_fe_mul(&E, &ZR_EDWARDS_A, &C);
+    zr_fe_add(&F, &E, &D);
+    zr_fe_square(&H, &p[2]);
+    zr_fe_mul(&t0, &two, &H);
+    zr_fe_sub(&J, &F, &t0);
+    zr_fe_sub(&t0, &B, &C);
+    zr_fe_sub(&t0, &t0, &D);
+    zr_fe_mul(&o[0], &t0, &J);
+    zr_fe_sub(&t0, &E, &D);
+    zr_fe_mul(&o[1], &F, &t0);
+    zr_fe_mul(&o[2], &F, &J);
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+}
+/* E:402-417: (X*Z, Y*Z, Z^2, X*Y) */
+void zr_proj_to_extended(zr_pt *r, const zr_fe p[3])
+{
+    zr_pt o;
+    zr_fe_mul(&o.X, &p[0], &p[2]);
+    zr_fe_mul(&o.Y, &p[1], &p[2]);
+    zr_fe_square(&o.Z, &p[2]);
+    zr_fe_mul(&o.T, &p[0], &p[1]);
+    *r = o;
+}
+/* R:205-222 */
+int zr_ris_is_valid(const zr_pt *p)
+{
+    zr_pt lp, id;
+    zr_ed_scalar_mul(&lp, p, &ZR_L);
+    zr_ed_identity(&id);
+    int has_order_l = zr_ed_eq(&lp, &id) == 1;
+    return has_order_l & zr_ed_is_valid(p);
+}
+/* R:493-507 */
+void zr_ris_from_uniform_bytes(zr_pt *r, const uint8_t b[64])
+{
+    zr_fe r1, r2;
+    zr_pt R1, R2;
+    zr_fe_from_bytes(&r1, b);
+    zr_ris_elligator(&R1, &r1);
+    zr_fe_from_bytes(&r2, b + 32);
+    zr_ris_elligator(&R2, &r2);
+    zr_ed_add(r, &R1, &R2);
+}
+
 /* ------------------------------------------------------------------ batch wrappers */
 #define FE(p, i) ((const zr_fe *)((p) + 5 * (i)))
 #define FEO(p, i) ((zr_fe *)((p) + 5 * (i)))
@@ -1097,6 +1176,20 @@ void zr_ris_roundtrip_mul_batch(const uint8_t *in, const uint64_t *k, uint8_t *o
         if (ok) ok[i] = (uint8_t)o;
     }
 }
+void zr_proj_add_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_proj_add((zr_fe *)(out + 15 * i), (const zr_fe *)(p + 15 * i), (const zr_fe *)(q + 15 * i)); }
+void zr_proj_double_batch(const uint64_t *p, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_proj_double((zr_fe *)(out + 15 * i), (const zr_fe *)(p + 15 * i)); }
+void zr_proj_to_extended_batch(const uint64_t *p, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_proj_to_extended(PTO(out, i), (const zr_fe *)(p + 15 * i)); }
+void zr_ed_is_valid_batch(const uint64_t *p, uint8_t *valid, size_t n)
+{ for (size_t i = 0; i < n; i++) valid[i] = (uint8_t)zr_ed_is_valid(PT(p, i)); }
+void zr_ris_is_valid_batch(const uint64_t *p, uint8_t *valid, size_t n)
+{ for (size_t i = 0; i < n; i++) valid[i] = (uint8_t)zr_ris_is_valid(PT(p, i)); }
+void zr_ris_elligator_batch(const uint64_t *r0, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) { zr_pt r; zr_ris_elligator(&r, FE(r0, i)); *PTO(out, i) = r; } }
+void zr_ris_from_uniform_bytes_batch(const uint8_t *in, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) { zr_pt r; zr_ris_from_uniform_bytes(&r, in + 64 * i); *PTO(out, i) = r; } }
 void zr_msm_naive(const uint64_t *p, const uint64_t *k, size_t n, uint64_t *out_point)
 {
     zr_pt acc, t;

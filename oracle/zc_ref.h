@@ -140,6 +140,18 @@ void zr_ris_compress_batch(const uint64_t *p, uint8_t *out, size_t n);
 void zr_ris_decompress_batch(const uint8_t *in, uint64_t *out, uint8_t *ok, size_t n);
 void zr_ris_eq_batch(const uint64_t *p, const uint64_t *q, uint8_t *eq, size_t n);
 void zr_ris_roundtrip_mul_batch(const uint8_t *in, const uint64_t *k, uint8_t *out, uint8_t *ok, size_t n);
+void zr_proj_add(zr_fe r[3], const zr_fe p[3], const zr_fe q[3]);
+void zr_proj_double(zr_fe r[3], const zr_fe p[3]);
+void zr_proj_to_extended(zr_pt *r, const zr_fe p[3]);
+int  zr_ris_is_valid(const zr_pt *p);
+void zr_ris_from_uniform_bytes(zr_pt *r, const uint8_t b[64]);
+void zr_proj_add_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
+void zr_proj_double_batch(const uint64_t *p, uint64_t *out, size_t n);
+void zr_proj_to_extended_batch(const uint64_t *p, uint64_t *out, size_t n);
+void zr_ed_is_valid_batch(const uint64_t *p, uint8_t *valid, size_t n);
+void zr_ris_is_valid_batch(const uint64_t *p, uint8_t *valid, size_t n);
+void zr_ris_elligator_batch(const uint64_t *r0, uint64_t *out, size_t n);
+void zr_ris_from_uniform_bytes_batch(const uint8_t *in, uint64_t *out, size_t n);
 /* sum_i k_i * P_i by the reference's own ops (scalar_mul then add, in index order) */
 void zr_msm_naive(const uint64_t *p, const uint64_t *k, size_t n, uint64_t *out_point);
 

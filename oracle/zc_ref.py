@@ -214,6 +214,44 @@ def ris_roundtrip_mul(b, k):
     return out, ok
 
 
+proj_add = _binop("zr_proj_add_batch", 15)
+proj_double = _unop("zr_proj_double_batch", 15)
+
+
+def proj_to_extended(p):
+    p = _u64(p, 15)
+    out = np.empty((p.shape[0], 20), dtype=np.uint64)
+    lib().zr_proj_to_extended_batch(_p(p), _p(out), C.c_size_t(p.shape[0]))
+    return out
+
+
+def _valid(name):
+    def f(p):
+        p = _u64(p, 20)
+        v = np.empty(p.shape[0], dtype=np.uint8)
+        getattr(lib(), name)(_p(p), _p(v), C.c_size_t(p.shape[0]))
+        return v
+    return f
+
+
+ed_is_valid = _valid("zr_ed_is_valid_batch")
+ris_is_valid = _valid("zr_ris_is_valid_batch")
+
+
+def ris_elligator(r0):
+    r0 = _u64(r0, 5)
+    out = np.empty((r0.shape[0], 20), dtype=np.uint64)
+    lib().zr_ris_elligator_batch(_p(r0), _p(out), C.c_size_t(r0.shape[0]))
+    return out
+
+
+def ris_from_uniform_bytes(b):
+    b = _u8(b, 64)
+    out = np.empty((b.shape[0], 20), dtype=np.uint64)
+    lib().zr_ris_from_uniform_bytes_batch(_p(b), _p(out), C.c_size_t(b.shape[0]))
+    return out
+
+
 def msm_naive(p, k):
     p, k = _u64(p, 20), _u64(k, 5)
     out = np.empty((1, 20), dtype=np.uint64)

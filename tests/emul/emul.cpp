@@ -142,3 +142,15 @@ extern "C" void emul_ed_scalar_mul_mode(const u64* p, const u64* k, u64* out, si
         pt_store(out + 20 * i, mode == 1 ? scalar_mul_ltr_seq<1>(P, l) : scalar_mul_ltr_seq<2>(P, l));
     }
 }
+extern "C" {
+void emul_ris_elligator(const u64* r0, u64* out, size_t n)
+{ for (size_t i = 0; i < n; i++) pt_store(out + 20 * i, ris_elligator(fe_load_mont<FP>(r0 + 5 * i))); }
+void emul_ed_is_valid(const u64* p, uint8_t* v, size_t n)
+{ for (size_t i = 0; i < n; i++) v[i] = ed_is_valid(pt_load(p + 20 * i)); }
+static ppt pld(const u64* p) { ppt r; r.X = fe_load_mont<FP>(p); r.Y = fe_load_mont<FP>(p + 5); r.Z = fe_load_mont<FP>(p + 10); return r; }
+static void pst(u64* o, const ppt& p) { fe_store_canon<FP>(o, p.X); fe_store_canon<FP>(o + 5, p.Y); fe_store_canon<FP>(o + 10, p.Z); }
+void emul_proj_add(const u64* p, const u64* q, u64* out, size_t n)
+{ for (size_t i = 0; i < n; i++) pst(out + 15 * i, proj_add(pld(p + 15 * i), pld(q + 15 * i))); }
+void emul_proj_double(const u64* p, u64* out, size_t n)
+{ for (size_t i = 0; i < n; i++) pst(out + 15 * i, proj_double(pld(p + 15 * i))); }
+}

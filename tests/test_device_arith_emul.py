@@ -157,3 +157,25 @@ def test_emul_codecs(emul, oracle):
     emul.emul_ed_decompress(p(rawq), p(dec), p(ok), C.c_size_t(200))
     wdec, wok = oracle.ed_decompress(raw)
     assert np.array_equal(ok, wok) and np.array_equal(dec, wdec) and 0 < ok.sum() < 200
+
+
+def test_emul_next_rows(emul, oracle, kats):
+    # Elligator (N3): the reference's Sage vector (non-canonical r0) plus random field elements
+    r0b = bytes.fromhex(kats["ristretto_elligator_hex"][0]["hex"])
+    r0 = oracle.fe_from_bytes(np.frombuffer(r0b, dtype=np.uint8).reshape(1, 32))
+    R = np.concatenate([r0, V.limbs_array(V.rand_fe(60, V.SEED + 15))])
+    out = np.empty((len(R), 20), dtype=np.uint64)
+    emul.emul_ris_elligator(p(R), p(out), C.c_size_t(len(R)))
+    assert np.array_equal(out, oracle.ris_elligator(R))
+    # is_valid and projective add/double (N4)
+    P = V.base_multiples(oracle, 32, V.SEED + 16)
+    P[1, 5] ^= np.uint64(1)                                       # knock one point off the curve
+    v = np.empty(32, dtype=np.uint8)
+    emul.emul_ed_is_valid(p(P), p(v), C.c_size_t(32))
+    assert np.array_equal(v, oracle.ed_is_valid(P)) and v[1] == 0 and v[0] == 1
+    A3, B3 = np.ascontiguousarray(P[:, :15]), np.ascontiguousarray(P[::-1, :15])
+    o3 = np.empty_like(A3)
+    emul.emul_proj_add(p(A3), p(B3), p(o3), C.c_size_t(32))
+    assert np.array_equal(o3, oracle.proj_add(A3, B3))
+    emul.emul_proj_double(p(A3), p(o3), C.c_size_t(32))
+    assert np.array_equal(o3, oracle.proj_double(A3))

@@ -315,6 +315,44 @@ def test_ristretto_roundtrip_mul(eng, oracle):
     assert eq(ok, wok) and eq(out, wout) and 0 < (ok == 0).sum() <= len(bad)
 
 
+def test_next_rows_elligator_validity_projective(eng, oracle, kats):
+    """Elligator + from_uniform_bytes, is_valid (Edwards and Ristretto),
+    ProjectivePoint add/double -- limb-exact vs the oracle, reference KATs included."""
+    r0b = bytes.fromhex(kats["ristretto_elligator_hex"][0]["hex"])
+    exp = np.array([sum([x["limbs"] for x in kats["ristretto_elligator_point"]], [])], dtype=np.uint64)
+    r0 = eng.fe_from_bytes(np.frombuffer(r0b, dtype=np.uint8).reshape(1, 32))
+    got = eng.ris_elligator(r0)
+    assert eng.ris_eq(got, exp)[0] == 1 and eq(eng.ris_compress(got), eng.ris_compress(exp))   # elligator_vs_ristretto_sage
+    R = V.rand_fe_np(3000, V.SEED + 110)
+    assert eq(eng.ris_elligator(R), oracle.ris_elligator(R))
+    rng = np.random.default_rng(V.SEED + 111)
+    ub = rng.integers(0, 256, size=(2000, 64), dtype=np.uint8)
+    pts = eng.ris_from_uniform_bytes(ub)
+    assert eq(pts, oracle.ris_from_uniform_bytes(ub))
+    assert eng.ed_is_valid(pts).all()                               # random_point_validity
+    P = V.base_multiples(oracle, 400, V.SEED + 112)
+    P[1, 5] ^= np.uint64(1)
+    assert eq(eng.ed_is_valid(P), oracle.ed_is_valid(P)) and eng.ed_is_valid(P)[1] == 0
+    # validity_check (ristretto.rs:642-664): multiples of B valid, the order-8L point is not
+    yb = np.array([kats["ristretto_inline_bytes"][0]["bytes"]], dtype=np.uint8)
+    yb2 = yb.copy()
+    p8, ok = eng.ed_decompress(yb2)                                 # sign 0, y < 2^252
+    assert ok[0] == 1 and eng.ed_is_valid(p8)[0] == 1
+    Q = np.concatenate([P[:64], p8, pts[:32]])
+    assert eq(eng.ris_is_valid(Q), oracle.ris_is_valid(Q))
+    assert eng.ris_is_valid(p8)[0] == 0 and eng.ris_is_valid(P[:1])[0] == 1
+    def pp(n):
+        c = kats["edwards_points"][n]["coords"]
+        return np.array([c["X"] + c["Y"] + c["Z"]], dtype=np.uint64)
+    assert eq(eng.proj_add(pp("P1_PROJECTIVE"), pp("P2_PROJECTIVE")), pp("P4_PROJECTIVE"))    # projective_point_addition
+    assert eq(eng.proj_double(pp("P1_PROJECTIVE")), pp("P3_PROJECTIVE"))                      # projective_point_doubling
+    c1 = kats["edwards_points"]["P1_EXTENDED"]["coords"]
+    assert eq(eng.proj_to_extended(pp("P1_PROJECTIVE")), np.array([c1["X"] + c1["Y"] + c1["Z"] + c1["T"]], dtype=np.uint64))
+    A3, B3 = np.ascontiguousarray(P[:, :15]), np.ascontiguousarray(P[::-1, :15])
+    assert eq(eng.proj_add(A3, B3), oracle.proj_add(A3, B3)) and eq(eng.proj_double(A3), oracle.proj_double(A3))
+    assert eq(eng.proj_to_extended(A3), oracle.proj_to_extended(A3))
+
+
 def test_msm_small(eng, oracle):
     for n in (1, 2, 3, 64, 257):                                  # scalar-mul + fold path
         P = V.base_multiples(oracle, n, V.SEED + 80 + n)
