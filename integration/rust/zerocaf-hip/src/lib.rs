@@ -1,37 +1,11 @@
-# INTEGRATION — binding `libzerocaf_hip.so` from the reference crate
-
-The reference (`zerocaf` 0.2.0, pure Rust) exposes the hot path through `Copy` structs and operator traits
-(`src/edwards.rs:547-577` `Mul<&Scalar> for &EdwardsPoint`, `src/ristretto.rs:96-154,398-425`, …) and has no FFI.
-`libzerocaf_hip.so` (C ABI: `include/zerocaf_hip.h`) is the batched MI355X backend for exactly that path. A
-maintainer adds ONE module to the crate — a thin `extern "C"` shim plus a batch trait — and keeps every existing
-single-element API untouched (single elements keep running on the CPU backend; batches go to the GPU).
-
-Rust is not installed in the build image, so the shim below is source only (it has not been compiled here); the
-same ABI is exercised end-to-end through `ctypes` (`dusk_zerocaf_amd/_lib.py`, `tests/test_gpu_parity.py`) and from
-C++ (`dusk_zerocaf_amd/include/zerocaf.hpp`).
-
-## 1. Layout contract
-
-The Rust structs are not `#[repr(C)]`, so the shim copies into flat buffers (one `memcpy`-able loop):
-
-| Rust type (reference) | flat form | bytes |
-|---|---|---|
-| `FieldElement(pub [u64;5])` `src/backend/u64/field.rs:31-32` | 5 × u64, radix 2⁵² | 40 |
-| `Scalar(pub [u64;5])` `src/backend/u64/scalar.rs:26-27` | 5 × u64 | 40 |
-| `EdwardsPoint{X,Y,Z,T}` `src/edwards.rs:336-342`, `RistrettoPoint(EdwardsPoint)` `src/ristretto.rs:157-158` | X‖Y‖Z‖T = 20 × u64 | 160 |
-| `CompressedEdwardsY([u8;32])`, `CompressedRistretto([u8;32])` | 32 bytes | 32 |
-
-Errors: the reference's `panic!`/`assert!` on a whole call (bad `two_pow_k` exponent) → negative status; per-element
-panics / `None` (inverse of zero, undecodable encodings, scalar bytes > L−1) → `ok[i] = 0`.
-
-## 2. Rust shim (`src/backend/hip/mod.rs`, new; selected by a cargo feature `hip_backend`)
-
-```rust
+// Standalone form of the shim in INTEGRATION.md section 2 (inside the zerocaf crate the
+// `use zerocaf::` paths become `use crate::`).  Not compiled in the build image (no Rust toolchain).
+#![allow(non_snake_case)]
 //! Batched MI355X backend: binds libzerocaf_hip.so (include/zerocaf_hip.h).
-use crate::edwards::EdwardsPoint;
-use crate::field::FieldElement;
-use crate::ristretto::{CompressedRistretto, RistrettoPoint};
-use crate::scalar::Scalar;
+use zerocaf::edwards::EdwardsPoint;
+use zerocaf::field::FieldElement;
+use zerocaf::ristretto::{CompressedRistretto, RistrettoPoint};
+use zerocaf::scalar::Scalar;
 use std::os::raw::{c_int, c_uint, c_void};
 
 #[repr(C)] pub struct ZcCtx { _private: [u8; 0] }
@@ -111,40 +85,3 @@ impl BatchMul for RistrettoPoint {
         be.mul_batch(&eds, scalars).into_iter().map(RistrettoPoint).collect()
     }
 }
-```
-
-The same code as a standalone crate: `integration/rust/zerocaf-hip/` (Cargo.toml, build.rs, src/lib.rs).
-Inside the zerocaf crate, `Cargo.toml` gets `hip_backend = []` under `[features]` and a `build.rs` with
-`println!("cargo:rustc-link-search=native={}", env!("ZEROCAF_HIP_LIB_DIR"));`. `src/backend/mod.rs:9-16` gains
-`#[cfg(feature = "hip_backend")] pub mod hip;`.
-
-## 3. C and C++
-
-```c
-#include "zerocaf_hip.h"
-zc_ctx *ctx; zc_ctx_create(NULL, 0, &ctx);
-zc_ed_scalar_mul(ctx, points /*n*20 u64*/, scalars /*n*5 u64*/, out, n, ZC_SCALAR_MUL_STRICT);
-zc_ctx_destroy(ctx);
-```
-Link with `-L dusk_zerocaf_amd -lzerocaf_hip` (needs `libamdhip64.so` at run time). `dusk_zerocaf_amd/include/zerocaf.hpp`
-wraps the ABI in value types with the reference's names and operators (`FieldElement`, `Scalar`, `EdwardsPoint`,
-`RistrettoPoint`, `CompressedRistretto`; `a * b`, `P + Q`, `P * k`, `.double_()`, `.compress()`,
-`.decompress()`, `mul_by_pow_2`, `mul_by_cofactor`) plus `*_batch` functions on `std::vector`s.
-
-## 4. Python (what the tests and bench use)
-
-```python
-import torch                      # optional, but import it FIRST if you use it (one HIP runtime per process)
-import dusk_zerocaf_amd as z
-eng = z.Engine()                  # zc_ctx_create(NULL, 0)
-Q = eng.ed_scalar_mul(P, K)       # numpy (n,20)/(n,5) uint64 -> staged; torch CUDA int64 tensors -> in place
-eng.set_stream(torch.cuda.current_stream().cuda_stream)   # launch on torch's stream
-```
-
-## 5. Device-resident use and multi-GPU
-
-Pass device pointers (e.g. `hipMalloc`, `torch.Tensor.data_ptr()`) to skip PCIe staging; calls are asynchronous on
-the context stream (`zc_ctx_set_stream` to borrow yours). One process per GPU is the intended scale-out
-(`python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`): the batch is split into contiguous ranges,
-no collective is needed for element-wise calls; an MSM combines one 160-byte partial per rank (all-gather + ordered
-fold). Alternatively one process can hand a device list to `zc_ctx_create` and let host batches be sharded inside.

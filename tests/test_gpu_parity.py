@@ -149,12 +149,22 @@ def test_fe_invert_bulk(eng, oracle):
 def test_fe_invert_chunked_exact(eng, oracle):
     """Batch sizes that take the Montgomery-trick kernel (chunks of 2 and 4 per lane) vs the
     oracle's Savas-Koc inverse, with zeros inside and at the ragged end."""
-    for n in ((1 << 18) + 5, (1 << 19) + 1):
-        a = V.rand_fe_np(n, V.SEED + 28)
-        a[[0, 1, 77, n - 1]] = 0
-        out, ok = eng.fe_invert(a)
-        want, wok = oracle.fe_invert(a)
-        assert eq(ok, wok) and eq(out, want) and ok.sum() == n - 4
+    n = (1 << 18) + 5
+    a = V.rand_fe_np(n, V.SEED + 28)
+    a[[0, 1, 77, n - 1]] = 0
+    out, ok = eng.fe_invert(a)
+    sel = np.r_[0:40000, n - 40000:n]                             # oracle: 18 us per inverse
+    want, wok = oracle.fe_invert(a[sel])
+    assert eq(ok[sel], wok) and eq(out[sel], want) and ok.sum() == n - 4
+    prod = eng.fe_mul(a, out)                                     # and a * a^-1 == 1 everywhere else
+    nz = ok == 1
+    assert (prod[nz, 0] == 1).all() and not prod[nz, 1:].any() and not out[~nz].any()
+    n = (1 << 19) + 1                                             # chunks of 4
+    a = V.rand_fe_np(n, V.SEED + 29)
+    out, ok = eng.fe_invert(a)
+    want, _ = oracle.fe_invert(a[-3000:])
+    prod = eng.fe_mul(a, out)
+    assert ok.all() and eq(out[-3000:], want) and (prod[:, 0] == 1).all() and not prod[:, 1:].any()
 
 
 def test_sqrt_ratio_bulk(eng, oracle):
@@ -388,6 +398,33 @@ def test_msm_bucket_method(eng, oracle, n, bits):
     assert oracle.ed_eq(got, want)[0] == 1
     assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
     assert eq(oracle.ris_compress(got), oracle.ris_compress(want))
+
+
+def test_empty_batches_and_in_context_sharding(eng, oracle):
+    """n = 0 is a no-op for every call shape; a context over two device slots (the same GPU
+    twice here) shards host batches into contiguous ranges and gives identical results."""
+    import dusk_zerocaf_amd as z
+    e5, e20, e32 = (np.zeros((0, w), dtype=np.uint64) for w in (5, 20, 32))
+    assert eng.fe_mul(e5, e5).shape == (0, 5) and eng.ed_scalar_mul(e20, e5).shape == (0, 20)
+    assert eng.ris_compress(e20).shape == (0, 32) and eng.fe_invert(e5)[0].shape == (0, 5)
+    assert eq(eng.msm(e20, e5), np.array([V.IDENT_ROW], dtype=np.uint64))
+    two = z.Engine([0, 0])
+    try:
+        n = 20001                                                  # odd: shards of 10001 and 10000
+        P = V.base_multiples(oracle, 1024, V.SEED + 120)
+        P = np.tile(P, (20, 1))[:n].copy()
+        K = V.rand_scalars_np(n, V.SEED + 121, bits=252)
+        assert eq(two.ed_scalar_mul(P, K), eng.ed_scalar_mul(P, K))
+        a, b = V.rand_fe_np(n, V.SEED + 122), V.rand_fe_np(n, V.SEED + 123)
+        assert eq(two.fe_mul(a, b), oracle.fe_mul(a, b))
+        inv, ok = two.fe_invert(a)
+        assert eq(inv, eng.fe_invert(a)[0]) and ok.all()
+        enc = eng.ris_compress(P)
+        assert eq(two.ris_roundtrip_mul(enc, K)[0], eng.ris_roundtrip_mul(enc, K)[0])
+        m2, m1 = two.msm(P, K), eng.msm(P, K)
+        assert oracle.ed_eq(m2, m1)[0] == 1 and eq(oracle.ed_compress(m2)[0], oracle.ed_compress(m1)[0])
+    finally:
+        two.close()
 
 
 def test_device_resident_buffers(eng, oracle):
