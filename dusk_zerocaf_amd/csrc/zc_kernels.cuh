@@ -391,23 +391,59 @@ ZC_KERNEL void k_sm_cost_scatter(const u64* k, u32* offsets, u32* idx, size_t n)
     if (i < n) idx[base[c] + rank] = (u32)i;
 }
 
+// ---- block-local lane balancing --------------------------------------------------------
+// Same idea as the global counting sort above, but inside one block: the 256 elements a block
+// owns are ranked by cost in LDS and lane j runs the element of rank j, so each of the four
+// waves gets a cost quartile.  A block still touches exactly its own contiguous 256 records
+// (HBM traffic stays algorithmic: the global permutation turns the 160-byte reads into line
+// gathers) and no prepass kernels or index buffers are needed; it gives up ~1 % of the steps a
+// batch-wide order saves.  Scalar words stay in the owner's LDS column, the executing lane reads
+// column `e`.  Returns the in-block element index this lane executes.
+ZC_DI int block_cost_rank(u32* __restrict__ skey, u32* __restrict__ sperm, u32 my_cost)
+{
+    const int tid = threadIdx.x;
+    skey[tid] = my_cost;
+    __syncthreads();
+    int rank = 0;
+    for (int u = 0; u < ZC_BLOCK; u++) {
+        const u32 c = skey[u];
+        rank += (c > my_cost || (c == my_cost && u < tid)) ? 1 : 0;
+    }
+    sperm[rank] = (u32)tid;
+    __syncthreads();
+    return (int)sperm[tid];
+}
+
 // k_stride = 5 (one scalar per point) or 0 (one scalar for the whole batch:
-// mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191).  idx: optional cost-sorted permutation.
+// mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191).
+// idx != nullptr: batch-wide cost-sorted permutation (k_sm_cost_*); otherwise block-local ranking.
 ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
+    __shared__ u32 skey[ZC_BLOCK];
+    __shared__ u32 sperm[ZC_BLOCK];
+    __shared__ int snb[ZC_BLOCK];
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
-    const size_t ii = valid ? (idx ? (size_t)idx[i] : i) : 0;
+    const size_t own = valid ? (idx ? (size_t)idx[i] : i) : 0;
     u64 l[5];
-    load5(l, k + k_stride * ii);
+    load5(l, k + k_stride * own);
     int nbits;
     scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     if (!valid) nbits = 0;
+    int e = tid;
+    if (!idx && k_stride != 0) {
+        snb[tid] = nbits;
+        e = block_cost_rank(skey, sperm, valid ? scalar_cost(l) : 0);
+        nbits = snb[e];
+    }
+    const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
+    const bool run = idx ? valid : (base + e < n);
+    const size_t ii = idx ? own : (run ? base + e : 0);
     const pt P = pt_load(p + 20 * ii);
-    const pt Q = scalar_mul_unified(P, sk + tid, ZC_BLOCK, nbits);
-    if (valid) pt_store(out + 20 * ii, Q);
+    const pt Q = scalar_mul_unified(P, sk + e, ZC_BLOCK, run ? nbits : 0);
+    if (run) pt_store(out + 20 * ii, Q);
 }
 
 // ltr_bin_mul (MODE 1) / binary_naf_mul (MODE 2): limbs identical to the reference's variants
@@ -499,22 +535,35 @@ ZC_KERNEL void k_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, const u32* idx, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
+    __shared__ u32 skey[ZC_BLOCK];
+    __shared__ u32 sperm[ZC_BLOCK];
+    __shared__ int snb[ZC_BLOCK];
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
-    const size_t ii = valid ? (idx ? (size_t)idx[i] : i) : 0;
+    const size_t own = valid ? (idx ? (size_t)idx[i] : i) : 0;
     u64 w[4], l[5];
-    load_words256(w, in + 32 * ii);
-    load5(l, k + 5 * ii);
+    load5(l, k + 5 * own);
     int nbits;
     scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
+    if (!valid) nbits = 0;
+    int e = tid;
+    if (!idx) {
+        snb[tid] = nbits;
+        e = block_cost_rank(skey, sperm, valid ? scalar_cost(l) : 0);
+        nbits = snb[e];
+    }
+    const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
+    const bool run = idx ? valid : (base + e < n);
+    const size_t ii = idx ? own : (run ? base + e : 0);
+    load_words256(w, in + 32 * ii);
     pt P;
     const bool dec = ris_decompress(P, w);
-    if (!valid || !dec) nbits = 0;
-    const pt Q = scalar_mul_unified(P, sk + tid, ZC_BLOCK, nbits);
+    if (!run || !dec) nbits = 0;
+    const pt Q = scalar_mul_unified(P, sk + e, ZC_BLOCK, nbits);
     fe_to_words256(w, ris_compress(Q));
     if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
-    if (valid) {
+    if (run) {
         store_words256(out + 32 * ii, w);
         if (ok) ok[ii] = dec ? 1 : 0;
     }

@@ -223,10 +223,17 @@ int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_
 
 // Cost-sorted permutation for the unified-step kernels (see zc_kernels.cuh "lane balancing").
 // Returns nullptr (natural order) for small batches or when scratch cannot be had.
+// ZC_BALANCE=global selects it; the default is the in-kernel block-local ranking, which keeps
+// HBM traffic algorithmic (a batch-wide permutation turns record reads into cache-line gathers).
 constexpr size_t BALANCE_MIN_N = 1 << 14;
+inline bool global_balance()
+{
+    static const bool g = [] { const char* e = getenv("ZC_BALANCE"); return e && std::string(e) == "global"; }();
+    return g;
+}
 const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt)
 {
-    if (cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
+    if (!global_balance() || cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
     const size_t need = zc::ZC_COST_BINS * sizeof(zc::u32) + cnt * sizeof(zc::u32);
     if (ensure(&D.bal, &D.bal_bytes, need) != ZC_OK) return nullptr;
     zc::u32* hist = (zc::u32*)D.bal;
