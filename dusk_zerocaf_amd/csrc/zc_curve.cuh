@@ -487,6 +487,22 @@ ZC_DI bool ed_compress(u64 (&w)[4], const pt& p)
     w[3] |= (u64)(sign ? 1 : 0) << 63;
     return ok;
 }
+// Tonelli-Shanks value of u/v with ONE exponentiation and no inversion: for p = 5 (mod 8),
+// (u v^3)(u v^7)^((p-5)/8) = (u/v)^((p+3)/8) = a^((q+1)/2) with a = u/v, q = (p-1)/4 -- exactly
+// the x the reference's mod_sqrt starts from (field.rs:410) -- and a^q = x^2 v / u, so the
+// correction by 6^q applies when v x^2 == -u.  Returns false where the reference returns None
+// (non-residue) ; v == 0 is reported separately (the reference's Div panics).  u, v R-class.
+ZC_DI bool fp_ts_sqrt_ratio(fe& x, const fe& u, const fe& v)
+{
+    const fe v3 = fp_mul(fp_sqr(v), v);
+    const fe v7 = fp_mul(fp_sqr(v3), v);
+    const fe x0 = fp_mul(fp_mul(u, v3), fp_pow(fp_mul(u, v7), ZC_EXP_P58, ModP::EXP_P58_BITS));
+    const fe check = fp_mul(v, fp_sqr(x0));
+    const bool t_is_one = fe_eq_canon(fp_canon(check), fp_canon(u));          // also u == 0 -> Some(0)
+    const bool t_is_m1 = fe_is_zero_canon(fp_canon(fe_add(check, u)));
+    x = fe_select(t_is_one, x0, fp_mul(x0, fe_const<FP>(ModP::SIX_POW_Q_M)));
+    return t_is_one || t_is_m1;
+}
 // Edwards decompress (edwards.rs:313-326, :962-979, :402-417): byte 31 masked with 0x0F
 ZC_DI bool ed_decompress(pt& out, const u64 (&win)[4])
 {
@@ -495,11 +511,11 @@ ZC_DI bool ed_decompress(pt& out, const u64 (&win)[4])
     const fe one = fe_one_m<FP>();
     const fe y = mont_to<FP>(fe_from_words256(w));
     const fe yy = fp_sqr(y);
-    const fe num = fp_sub(yy, one);
-    const fe den = fe_add(fp_mul(fe_const<FP>(ModP::D_M), yy), one);
-    const fe xx = fp_mul(num, fp_invert(den));
-    fe x;
-    const bool have = fp_mod_sqrt(x, xx, sign);
+    const fe num = fe_reduce<FP>(fp_sub(yy, one));                            // y^2 - 1
+    const fe den = fe_reduce<FP>(fe_add(fp_mul(fe_const<FP>(ModP::D_M), yy), one));   // d y^2 + 1
+    fe r;
+    const bool have = fp_ts_sqrt_ratio(r, num, den);
+    const fe x = fe_select(sign, fe_reduce<FP>(fp_neg(r)), r);                // mod_sqrt(xx, sign), field.rs:435-439
     out.X = x;
     out.Y = y;
     out.Z = one;

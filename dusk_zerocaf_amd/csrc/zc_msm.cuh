@@ -4,7 +4,8 @@
 //   1. k_msm_digits   : c-bit window digits -> (key = window << c | digit, value = point index)
 //   2. rocPRIM radix sort of the n*W pairs by key (c + log2 W bits)
 //   3. k_msm_bounds   : [start, end) of every bucket in the sorted list
-//   0. k_msm_prepare  : points -> cached form (Y-X, Y+X, Z, 2dT) in Montgomery radix-2^29 (144 B)
+//   0. k_msm_prepare  : points -> cached form (Y-X, Y+X, Z, 2dT), Montgomery domain, packed to
+//                       one 128-byte cache line per point
 //   4. k_msm_counts + rocPRIM sort of the bucket ids by population (descending), then
 //      k_msm_accumulate: one lane per bucket, lanes of a wave get equally full buckets; each
 //      point costs one 8-multiplication a = -1 addition against the cached form
@@ -53,42 +54,57 @@ ZC_KERNEL void k_msm_bounds(const u32* keys, u32* start, u32* end, size_t m)
 }
 
 // Cached ("projective Niels") form of an input point for the bucket sums: (Y-X, Y+X, Z, 2dT),
-// Montgomery radix 2^29, 4 x 9 u32 = 144 bytes.  MSM results are compared as group elements,
+// Montgomery domain.  MSM results are compared as group elements,
 // so the bucket sums are free to use the cheaper dedicated a = -1 addition (HWCD'08 sec. 3.1,
 // 8 multiplications against a cached operand) instead of the reference's 10-multiplication
 // sequence; the sum is the same group element.
 struct niels {
     fe ymx, ypx, z, t2d;
 };
+// A cached point is stored as 4 x 256-bit saturated words = 128 bytes = exactly one cache line
+// (all four values are < 2^256): the bucket sums gather these records at random, so one line
+// per record instead of 2.25 (144-byte records at arbitrary offsets) halves the gather traffic.
+ZC_DI void pack256(u32* __restrict__ o, const fe& a)       // normalized limbs -> 8 x u32
+{
+    u64 w[4];
+    fe_to_words256(w, a);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        o[2 * j] = (u32)w[j];
+        o[2 * j + 1] = (u32)(w[j] >> 32);
+    }
+}
+ZC_DI fe unpack256(const uint4 lo, const uint4 hi)
+{
+    const u64 w[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                      (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
+    return fe_from_words256(w);
+}
 ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
     const pt p = pt_load(points + 20 * i);
     const fe two_d = fe_reduce<FP>(fe_add(fe_const<FP>(ModP::D_M), fe_const<FP>(ModP::D_M)));
-    fe ymx = fp_sub(p.Y, p.X);
+    const fe ymx = fp_sub(p.Y, p.X);                       // normalized, < 7N < 2^256
     fe ypx = fe_add(p.Y, p.X);
     fe_carry(ypx);
+    fe z = p.Z;                                            // R-class: limbs 0..7 < 2^29
     const fe t2d = fp_mul(p.T, two_d);
-    u32* o = cached + 36 * i;
-#pragma unroll
-    for (int w = 0; w < 9; w++) {
-        o[w] = ymx.v[w];
-        o[9 + w] = ypx.v[w];
-        o[18 + w] = p.Z.v[w];
-        o[27 + w] = t2d.v[w];
-    }
+    u32* o = cached + 32 * i;
+    pack256(o, ymx);
+    pack256(o + 8, ypx);
+    pack256(o + 16, z);
+    pack256(o + 24, t2d);
 }
 ZC_DI niels niels_load(const u32* __restrict__ c)
 {
+    const uint4* v = reinterpret_cast<const uint4*>(c);   // 128-byte aligned record
     niels q;
-#pragma unroll
-    for (int w = 0; w < 9; w++) {
-        q.ymx.v[w] = c[w];
-        q.ypx.v[w] = c[9 + w];
-        q.z.v[w] = c[18 + w];
-        q.t2d.v[w] = c[27 + w];
-    }
+    q.ymx = unpack256(v[0], v[1]);
+    q.ypx = unpack256(v[2], v[3]);
+    q.z = unpack256(v[4], v[5]);
+    q.t2d = unpack256(v[6], v[7]);
     return q;
 }
 // p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square)
@@ -135,13 +151,13 @@ ZC_KERNEL void k_msm_accumulate(const u32* cached, const u32* vals, const u32* s
         // e+2 are in flight while point e is being added
         const u32 lo = start[b], hi = end[b];
         if (lo < hi) {
-            niels cur = niels_load(cached + 36 * (size_t)vals[lo]);
+            niels cur = niels_load(cached + 32 * (size_t)vals[lo]);
             u32 inext = (lo + 1 < hi) ? vals[lo + 1] : 0;
             for (u32 e = lo; e < hi; e++) {
                 const u32 iload = inext;
                 inext = (e + 2 < hi) ? vals[e + 2] : 0;
                 niels nxt = cur;
-                if (e + 1 < hi) nxt = niels_load(cached + 36 * (size_t)iload);
+                if (e + 1 < hi) nxt = niels_load(cached + 32 * (size_t)iload);
                 acc = pt_add_cached(acc, cur);
                 cur = nxt;
             }

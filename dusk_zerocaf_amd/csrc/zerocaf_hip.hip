@@ -333,7 +333,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         zc::u32* bcnt1 = cv.take<zc::u32>(nb);
         zc::u32* bid0 = cv.take<zc::u32>(nb);
         zc::u32* bid1 = cv.take<zc::u32>(nb);
-        zc::u32* cached = cv.take<zc::u32>(cnt * 36);
+        zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         u64* buckets = cv.take<u64>(nb * 20);
         u64* seg_sum = cv.take<u64>(nseg * 20);
         u64* seg_acc = cv.take<u64>(nseg * 20);
