@@ -223,12 +223,15 @@ def main():
             mad_peak = float(u["v_mad_u64_u32_lane_ops_per_s"])
             alu_peak = float(u["v_add_u32_lane_ops_per_s"])
             insts = float(json.load(open(pmc))["scalar_mul_valu_insts_per_launch"]) * n / (1 << 20)
-            # instruction mix of one unified step (ISA histogram of k_ed_scalar_mul): 10 x (126
-            # v_mad_u64_u32 + 9 v_mul_lo_u32 + 52 64-bit shift/add) at the mad rate, rest 32-bit ALU
-            heavy = 10 * (126 + 9 + 52) / 2450.0
+            # instruction mix of one unified step (ISA histogram of k_ed_scalar_mul): 10 Montgomery
+            # multiplications x (135 v_mad_u64_u32 + 9 v_mul_lo_u32 + 32 64-bit shift/add), the
+            # rest 32-bit ALU; ubench rates for the slow class (~5 cycles) and the fast class (2.5)
+            heavy = 10 * (135 + 9 + 32) / 2420.0
             t_min = insts * 64 * (heavy / mad_peak + (1 - heavy) / alu_peak)
             roofline["valu"] = {
-                "note": "this kernel is integer-VALU issue bound, not HBM bound (0.2% of HBM peak is expected)",
+                "note": "this kernel is integer-VALU issue bound, not HBM bound (0.2% of HBM peak is expected); "
+                        "issue_bound_ms = PMC instruction count x microbenchmarked issue rates, >1.0 means the "
+                        "kernel issues faster than the dependent-chain microbenchmark",
                 "valu_wave_insts_per_launch": insts, "mad_class_fraction": round(heavy, 3),
                 "v_mad_u64_u32_peak_lane_ops_per_s": mad_peak, "alu32_peak_lane_ops_per_s": alu_peak,
                 "issue_bound_ms": round(t_min * 1e3, 3),
