@@ -5,6 +5,6 @@ of include/zerocaf_hip.h).  This package only loads it and mirrors the reference
 operator surface for batches.  No CPU fallback exists.
 """
 from ._lib import ZerocafHipError, load, LIB_PATH, ALL_SYMBOLS  # noqa: F401
-from .engine import Engine, STRICT, LTR_BIN, BINARY_NAF  # noqa: F401
+from .engine import Engine, STRICT, LTR_BIN, BINARY_NAF, FAST  # noqa: F401
 
-__all__ = ["Engine", "STRICT", "LTR_BIN", "BINARY_NAF", "ZerocafHipError", "load", "LIB_PATH", "ALL_SYMBOLS"]
+__all__ = ["Engine", "STRICT", "LTR_BIN", "BINARY_NAF", "FAST", "ZerocafHipError", "load", "LIB_PATH", "ALL_SYMBOLS"]

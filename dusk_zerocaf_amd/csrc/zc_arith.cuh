@@ -316,6 +316,37 @@ ZC_DI void fe_store_canon(u64* __restrict__ p, const fe& a)
     for (int i = 0; i < 5; i++) p[i] = l[i];
 }
 
+// 32 little-endian bytes (as four u64 words) -> nine 29-bit limbs, all 256 bits kept
+// (from_bytes keeps bits 208..255 in the top limb: field.rs:563-587)
+ZC_DI fe fe_from_words256(const u64 (&w)[4])
+{
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, idx = bit >> 6, sh = bit & 63;
+        u64 x = w[idx] >> sh;
+        if (sh + 29 > 64 && idx + 1 < 4) x |= w[idx + 1] << (64 - sh);
+        r.v[k] = (k < 8) ? ((u32)x & M29) : (u32)x;
+    }
+    return r;
+}
+// canonical nine 29-bit limbs -> four u64 words (to_bytes, field.rs:591-631)
+ZC_DI void fe_to_words256(u64 (&w)[4], const fe& c)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int lo = 29 * k - 64 * j;
+            if (lo > -29 && lo < 64) {
+                if (lo >= 0) acc |= (u64)c.v[k] << lo;
+                else acc |= (u64)c.v[k] >> (-lo);
+            }
+        }
+        w[j] = acc;
+    }
+}
 // ---------------------------------------------------------------- fixed exponentiation
 // a^e for a compile-time exponent e (wave-uniform control flow), left-to-right
 // binary.  Replaces the reference's data-dependent Pow / Savas-Koc / Tonelli

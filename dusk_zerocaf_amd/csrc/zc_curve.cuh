@@ -347,38 +347,186 @@ ZC_DI int ltr_digits(u32* __restrict__ pos_bits, u32* __restrict__ neg_bits, int
     return top;
 }
 
-// ---------------------------------------------------------------- byte codecs
-// 32 little-endian bytes (as four u64 words) -> nine 29-bit limbs, all 256 bits kept
-// (from_bytes keeps bits 208..255 in the top limb: field.rs:563-587)
-ZC_DI fe fe_from_words256(const u64 (&w)[4])
+// ---------------------------------------------------------------- cached points, fast scalar-mul
+struct niels {
+    fe ymx, ypx, z, t2d;
+};
+// A cached point is stored as 4 x 256-bit saturated words = 128 bytes = exactly one cache line
+// (all four values are < 2^256): the bucket sums gather these records at random, so one line
+// per record instead of 2.25 (144-byte records at arbitrary offsets) halves the gather traffic.
+ZC_DI void pack256(u32* __restrict__ o, const fe& a)       // normalized limbs -> 8 x u32
 {
-    fe r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int bit = 29 * k, idx = bit >> 6, sh = bit & 63;
-        u64 x = w[idx] >> sh;
-        if (sh + 29 > 64 && idx + 1 < 4) x |= w[idx + 1] << (64 - sh);
-        r.v[k] = (k < 8) ? ((u32)x & M29) : (u32)x;
-    }
-    return r;
-}
-// canonical nine 29-bit limbs -> four u64 words (to_bytes, field.rs:591-631)
-ZC_DI void fe_to_words256(u64 (&w)[4], const fe& c)
-{
+    u64 w[4];
+    fe_to_words256(w, a);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        u64 acc = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int lo = 29 * k - 64 * j;
-            if (lo > -29 && lo < 64) {
-                if (lo >= 0) acc |= (u64)c.v[k] << lo;
-                else acc |= (u64)c.v[k] >> (-lo);
-            }
-        }
-        w[j] = acc;
+        o[2 * j] = (u32)w[j];
+        o[2 * j + 1] = (u32)(w[j] >> 32);
     }
 }
+ZC_DI fe unpack256(const uint4 lo, const uint4 hi)
+{
+    const u64 w[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                      (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
+    return fe_from_words256(w);
+}
+ZC_DI niels niels_from_pt(const pt& p)                 // p R-class
+{
+    const fe two_d = fe_reduce<FP>(fe_add(fe_const<FP>(ModP::D_M), fe_const<FP>(ModP::D_M)));
+    niels q;
+    q.ymx = fp_sub(p.Y, p.X);                              // normalized, < 7N < 2^256
+    q.ypx = fe_add(p.Y, p.X);
+    fe_carry(q.ypx);
+    q.z = p.Z;
+    q.t2d = fp_mul(p.T, two_d);
+    return q;
+}
+ZC_DI niels niels_identity()
+{
+    niels q;
+    q.ymx = fe_one_m<FP>();
+    q.ypx = fe_one_m<FP>();
+    q.z = fe_one_m<FP>();
+    q.t2d = fe_zero();
+    return q;
+}
+// -q: swap (Y-X, Y+X), negate 2dT
+ZC_DI niels niels_cond_neg(bool neg, const niels& q)
+{
+    niels r;
+    r.ymx = fe_select(neg, q.ypx, q.ymx);
+    r.ypx = fe_select(neg, q.ymx, q.ypx);
+    r.z = q.z;
+    r.t2d = fe_select(neg, fp_neg(q.t2d), q.t2d);          // q.t2d is R-class (a product)
+    return r;
+}
+ZC_DI void niels_store(u32* __restrict__ o, const niels& q)
+{
+    pack256(o, q.ymx);
+    pack256(o + 8, q.ypx);
+    pack256(o + 16, q.z);
+    pack256(o + 24, q.t2d);
+}
+ZC_DI niels niels_load(const u32* __restrict__ c)
+{
+    const uint4* v = reinterpret_cast<const uint4*>(c);   // 128-byte aligned record
+    niels q;
+    q.ymx = unpack256(v[0], v[1]);
+    q.ypx = unpack256(v[2], v[3]);
+    q.z = unpack256(v[4], v[5]);
+    q.t2d = unpack256(v[6], v[7]);
+    return q;
+}
+// p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square)
+ZC_DI pt pt_add_cached(const pt& p, const niels& q)
+{
+    const fe A = fp_mul(fp_sub(p.Y, p.X), q.ymx);
+    const fe B = fp_mul(fe_add(p.Y, p.X), q.ypx);
+    const fe C = fp_mul(p.T, q.t2d);
+    const fe ZZ = fp_mul(p.Z, q.z);
+    fe D = fe_add(ZZ, ZZ);
+    fe_carry(D);
+    const fe E = fp_sub(B, A);
+    const fe F = fp_sub(D, C);
+    const fe G = fe_add(D, C);
+    const fe H = fe_add(B, A);
+    pt r;
+    r.X = fp_mul(E, F);
+    r.Y = fp_mul(G, H);
+    r.Z = fp_mul(F, G);
+    r.T = fp_mul(E, H);
+    return r;
+}
+
+// Dedicated doubling, a = -1 (HWCD'08 sec. 3.3 "dbl-2008-hwcd"): 4S + 3M, + 1M when T is wanted.
+// Used only where results are compared as group elements or leave as canonical encodings.
+template <bool WITH_T>
+ZC_DI pt pt_double_fast(const pt& p)
+{
+    const fe A = fp_sqr(p.X);
+    const fe B = fp_sqr(p.Y);
+    const fe ZZ = fp_sqr(p.Z);
+    const fe E = fp_sub(fp_sub(fp_sqr(fe_add(p.X, p.Y)), A), B);     // 2XY
+    const fe G = fp_sub(B, A);                                         // D + B with D = a*A = -A
+    const fe F = fp_sub(fp_sub(G, ZZ), ZZ);                            // G - 2Z^2
+    const fe H = fp_sub(fp_neg(A), B);                                 // D - B
+    pt r;
+    r.X = fp_mul(E, F);
+    r.Y = fp_mul(G, H);
+    r.Z = fp_mul(F, G);
+    if (WITH_T) r.T = fp_mul(E, H);
+    else r.T = p.T;
+    return r;
+}
+
+// Signed radix-16 digits of the 260-bit scalar, d_i in [-8, 8), 66 digits (carry included),
+// stored as bytes at dig[i * stride]; returns the index of the highest non-zero digit or -1.
+ZC_DI int scalar_digits16(int8_t* __restrict__ dig, int stride, const u64 (&l)[5])
+{
+    u32 w[9];
+    int nb;
+    {
+        u32 tmp[9];
+        scalar_to_words(tmp, 1, l, nb);
+#pragma unroll
+        for (int k = 0; k < 9; k++) w[k] = tmp[k];
+    }
+    int carry = 0, top = -1;
+    for (int i = 0; i < 66; i++) {
+        const int word = i >> 3, sh = (i & 7) * 4;
+        int d = (word < 9 ? (int)((w[word] >> sh) & 15u) : 0) + carry;
+        carry = d >= 8;
+        d -= carry << 4;
+        dig[i * stride] = (int8_t)d;
+        if (d != 0) top = i;
+    }
+    return top;
+}
+
+// k * P with fixed signed 4-bit windows over a per-lane table {1P..8P} of cached points in
+// global scratch (8 x 128 bytes per point, one cache line per entry).  Uniform control flow:
+// every lane of a wave runs the same schedule from window `top` (wave-uniform) down to 0.
+// NOT the reference's formula sequence: the result equals double_and_add's as a group element
+// (identical affine coordinates / encodings), its (X:Y:Z:T) limbs differ by a projective factor.
+ZC_DI pt scalar_mul_fast(const pt& P, u32* __restrict__ table, const int8_t* __restrict__ dig, int stride, int top)
+{
+    // table[j] = (j + 1) P, cached form
+    {
+        const niels c1 = niels_from_pt(P);
+        niels_store(table, c1);
+        const pt p2 = pt_double_fast<true>(P);
+        niels_store(table + 32, niels_from_pt(p2));
+        const pt p3 = pt_add_cached(p2, c1);
+        niels_store(table + 64, niels_from_pt(p3));
+        const pt p4 = pt_double_fast<true>(p2);
+        niels_store(table + 96, niels_from_pt(p4));
+        const pt p5 = pt_add_cached(p4, c1);
+        niels_store(table + 128, niels_from_pt(p5));
+        const pt p6 = pt_double_fast<true>(p3);
+        niels_store(table + 160, niels_from_pt(p6));
+        const pt p7 = pt_add_cached(p6, c1);
+        niels_store(table + 192, niels_from_pt(p7));
+        const pt p8 = pt_double_fast<true>(p4);
+        niels_store(table + 224, niels_from_pt(p8));
+    }
+    pt Q = pt_identity();
+    for (int i = top; i >= 0; i--) {
+        if (i != top) {
+            Q = pt_double_fast<false>(Q);
+            Q = pt_double_fast<false>(Q);
+            Q = pt_double_fast<false>(Q);
+            Q = pt_double_fast<true>(Q);
+        }
+        const int d = dig[i * stride];
+        const int mag = d < 0 ? -d : d;
+        niels c = niels_identity();
+        if (mag != 0) c = niels_load(table + 32 * (mag - 1));
+        Q = pt_add_cached(Q, niels_cond_neg(d < 0, c));
+    }
+    return Q;
+}
+
+// ---------------------------------------------------------------- byte codecs
 // plain 256-bit value <= (p-1)/2 ?  (is_positive on the raw decoded limbs, ristretto.rs:104-114)
 ZC_DI bool words256_is_positive(const fe& raw)
 {

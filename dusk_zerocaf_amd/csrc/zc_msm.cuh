@@ -58,76 +58,12 @@ ZC_KERNEL void k_msm_bounds(const u32* keys, u32* start, u32* end, size_t m)
 // so the bucket sums are free to use the cheaper dedicated a = -1 addition (HWCD'08 sec. 3.1,
 // 8 multiplications against a cached operand) instead of the reference's 10-multiplication
 // sequence; the sum is the same group element.
-struct niels {
-    fe ymx, ypx, z, t2d;
-};
-// A cached point is stored as 4 x 256-bit saturated words = 128 bytes = exactly one cache line
-// (all four values are < 2^256): the bucket sums gather these records at random, so one line
-// per record instead of 2.25 (144-byte records at arbitrary offsets) halves the gather traffic.
-ZC_DI void pack256(u32* __restrict__ o, const fe& a)       // normalized limbs -> 8 x u32
-{
-    u64 w[4];
-    fe_to_words256(w, a);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        o[2 * j] = (u32)w[j];
-        o[2 * j + 1] = (u32)(w[j] >> 32);
-    }
-}
-ZC_DI fe unpack256(const uint4 lo, const uint4 hi)
-{
-    const u64 w[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
-                      (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
-    return fe_from_words256(w);
-}
 ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    const pt p = pt_load(points + 20 * i);
-    const fe two_d = fe_reduce<FP>(fe_add(fe_const<FP>(ModP::D_M), fe_const<FP>(ModP::D_M)));
-    const fe ymx = fp_sub(p.Y, p.X);                       // normalized, < 7N < 2^256
-    fe ypx = fe_add(p.Y, p.X);
-    fe_carry(ypx);
-    fe z = p.Z;                                            // R-class: limbs 0..7 < 2^29
-    const fe t2d = fp_mul(p.T, two_d);
-    u32* o = cached + 32 * i;
-    pack256(o, ymx);
-    pack256(o + 8, ypx);
-    pack256(o + 16, z);
-    pack256(o + 24, t2d);
+    niels_store(cached + 32 * i, niels_from_pt(pt_load(points + 20 * i)));
 }
-ZC_DI niels niels_load(const u32* __restrict__ c)
-{
-    const uint4* v = reinterpret_cast<const uint4*>(c);   // 128-byte aligned record
-    niels q;
-    q.ymx = unpack256(v[0], v[1]);
-    q.ypx = unpack256(v[2], v[3]);
-    q.z = unpack256(v[4], v[5]);
-    q.t2d = unpack256(v[6], v[7]);
-    return q;
-}
-// p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square)
-ZC_DI pt pt_add_cached(const pt& p, const niels& q)
-{
-    const fe A = fp_mul(fp_sub(p.Y, p.X), q.ymx);
-    const fe B = fp_mul(fe_add(p.Y, p.X), q.ypx);
-    const fe C = fp_mul(p.T, q.t2d);
-    const fe ZZ = fp_mul(p.Z, q.z);
-    fe D = fe_add(ZZ, ZZ);
-    fe_carry(D);
-    const fe E = fp_sub(B, A);
-    const fe F = fp_sub(D, C);
-    const fe G = fe_add(D, C);
-    const fe H = fe_add(B, A);
-    pt r;
-    r.X = fp_mul(E, F);
-    r.Y = fp_mul(G, H);
-    r.Z = fp_mul(F, G);
-    r.T = fp_mul(E, H);
-    return r;
-}
-
 // population of every bucket (0 for digit 0, which carries no weight) and its id
 ZC_KERNEL void k_msm_counts(const u32* start, const u32* end, u32* count, u32* ids, size_t nbuckets, int c)
 {

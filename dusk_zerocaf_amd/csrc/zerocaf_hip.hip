@@ -55,6 +55,8 @@ struct DevState {
     size_t bal_bytes = 0;
     void* msm = nullptr;                // bucket-method workspace (zc_msm)
     size_t msm_bytes = 0;
+    void* fast = nullptr;               // fast scalar-mul window tables: 1 KB per lane
+    size_t fast_bytes = 0;
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -453,6 +455,7 @@ int zc_ctx_destroy(zc_ctx* ctx)
             if (ds.tmp[a]) (void)hipFree(ds.tmp[a]);
         if (ds.bal) (void)hipFree(ds.bal);
         if (ds.msm) (void)hipFree(ds.msm);
+        if (ds.fast) (void)hipFree(ds.fast);
         if (ds.stream) (void)hipStreamDestroy(ds.stream);
     }
     delete ctx;
@@ -551,6 +554,18 @@ int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {
     if (flags == ZC_SCALAR_MUL_STRICT) return scalar_mul_impl(ctx, p, k, false, out, n);
+    if (flags == ZC_SCALAR_MUL_FAST) {
+        REQUIRE(p); REQUIRE(k); REQUIRE(out);
+        Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
+        int inner = ZC_OK;
+        int rc = run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+            const size_t lanes = (size_t)grid_for(cnt) * zc::ZC_BLOCK;
+            if ((inner = ensure(&D.fast, &D.fast_bytes, lanes * 1024)) != ZC_OK) return;
+            hipLaunchKernelGGL(zc::k_ed_scalar_mul_fast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
+                               (const u64*)d[1], (size_t)5, (u64*)d[2], (zc::u32*)D.fast, cnt);
+        });
+        return rc ? rc : inner;
+    }
     if (flags == ZC_SCALAR_MUL_LTR_BIN) return binop(ctx, zc::k_ed_scalar_mul_ltr_bin, nullptr, p, k, out, n, 0);
     if (flags == ZC_SCALAR_MUL_BINARY_NAF) return binop(ctx, zc::k_ed_scalar_mul_naf, nullptr, p, k, out, n, 0);
     return fail(ZC_ERR_BAD_ARG, "unknown scalar_mul flags");
@@ -648,10 +663,21 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
 {
     REQUIRE(in32); REQUIRE(k); REQUIRE(out32);
     Arg args[4] = {in_arg(in32, 32), in_arg(k, 40), out_arg(out32, 32), out_arg(ok, 1)};
-    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
-        const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
-        hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
+    // The boundary is encodings in / encodings out, which depend only on the group element, so
+    // the fast scalar-mul core is used (ZC_RISTRETTO_STRICT=1 runs the reference formula sequence).
+    static const bool strict = [] { const char* e = getenv("ZC_RISTRETTO_STRICT"); return e && atoi(e) != 0; }();
+    int inner = ZC_OK;
+    int rc = run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
+        if (strict) {
+            const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
+            hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
+            return;
+        }
+        const size_t lanes = (size_t)grid_for(cnt) * zc::ZC_BLOCK;
+        if ((inner = ensure(&D.fast, &D.fast_bytes, lanes * 1024)) != ZC_OK) return;
+        hipLaunchKernelGGL(zc::k_ris_roundtrip_mul_fast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], (zc::u32*)D.fast, cnt);
     });
+    return rc ? rc : inner;
 }
 
 // ---- "next" rows (N3, N4)

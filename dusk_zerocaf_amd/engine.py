@@ -18,6 +18,7 @@ from . import _lib
 STRICT = 0          # double_and_add (Mul<Scalar>)
 LTR_BIN = 1         # ltr_bin_mul
 BINARY_NAF = 2      # binary_naf_mul
+FAST = 16           # same group element, not limb-exact (windowed, dedicated doubling)
 
 
 def _is_torch(x) -> bool:

@@ -57,6 +57,10 @@ typedef enum zc_status {
 #define ZC_SCALAR_MUL_STRICT 0u      /* double_and_add = Mul<Scalar>, src/edwards.rs:102-120     */
 #define ZC_SCALAR_MUL_LTR_BIN 1u     /* ltr_bin_mul, src/edwards.rs:122-134 (reads bits 248..0)  */
 #define ZC_SCALAR_MUL_BINARY_NAF 2u  /* binary_naf_mul, src/edwards.rs:136-153 (canonical k < L) */
+/* NOT limb-exact: fixed signed windows + dedicated doubling.  The result is the same group
+ * element as Mul<Scalar> (== per src/edwards.rs:360-370, identical compress()/Ristretto bytes);
+ * its (X:Y:Z:T) limbs differ by a projective factor.  ~1.6x the strict throughput.          */
+#define ZC_SCALAR_MUL_FAST 16u
 
 /* ---- context -------------------------------------------------------------- */
 /* devices == NULL / ndev == 0: use the current HIP device.  With ndev > 1, calls on
@@ -129,7 +133,8 @@ int zc_ris_compress(zc_ctx *ctx, const uint64_t *p, uint8_t *out32, size_t n);
 int zc_ris_decompress(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, uint8_t *ok, size_t n);
 int zc_ris_eq(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint8_t *eq_out, size_t n);
 /* fused decompress -> Mul<Scalar> -> compress (ristretto.rs:96-154, :330-392, :398-425);
- * undecodable input -> ok = 0, out32 = 0                                           */
+ * undecodable input -> ok = 0, out32 = 0.  Outputs are encodings, which depend only on the
+ * group element: bit-identical to the reference whichever scalar-mul schedule runs inside.   */
 int zc_ris_roundtrip_mul(zc_ctx *ctx, const uint8_t *in32, const uint64_t *k, uint8_t *out32,
                          uint8_t *ok, size_t n);
 

@@ -154,3 +154,14 @@ void emul_proj_add(const u64* p, const u64* q, u64* out, size_t n)
 void emul_proj_double(const u64* p, u64* out, size_t n)
 { for (size_t i = 0; i < n; i++) pst(out + 15 * i, proj_double(pld(p + 15 * i))); }
 }
+extern "C" void emul_ed_scalar_mul_fast(const u64* p, const u64* k, u64* out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 l[5];
+        ld5(l, k + 5 * i);
+        alignas(128) u32 table[256];
+        int8_t dig[66];
+        const int top = scalar_digits16(dig, 1, l);
+        pt_store(out + 20 * i, scalar_mul_fast(pt_load(p + 20 * i), table, dig, 1, top));
+    }
+}

@@ -110,6 +110,12 @@ def test_emul_point_ops(emul, oracle):
     for mode in (1, 2):                                         # ltr_bin_mul / binary_naf_mul limbs
         emul.emul_ed_scalar_mul_mode(p(P), p(Kc), p(out), C.c_size_t(n), mode)
         assert np.array_equal(out, oracle.ed_scalar_mul_mode(P, Kc, mode)), mode
+    fast = np.empty_like(P)                                     # fast mode: same group element
+    emul.emul_ed_scalar_mul_fast(p(P), p(K), p(fast), C.c_size_t(n))
+    want = oracle.ed_scalar_mul(P, K)
+    assert oracle.ed_eq(fast, want).all() and not np.array_equal(fast, want)
+    assert np.array_equal(oracle.ed_compress(fast)[0], oracle.ed_compress(want)[0])
+    assert np.array_equal(oracle.ris_compress(fast), oracle.ris_compress(want))
     emul.emul_ed_scalar_mul(p(P), p(K), p(out), C.c_size_t(n))
     xy, ok = np.empty((n, 10), dtype=np.uint64), np.empty(n, dtype=np.uint8)
     emul.emul_ed_to_affine(p(out), p(xy), p(ok), C.c_size_t(n))

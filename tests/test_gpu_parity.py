@@ -253,6 +253,27 @@ def test_scalar_mul_reference_variants(eng, oracle, mode):
     assert eng.ed_eq(got, eng.ed_scalar_mul(P, K)).all()
 
 
+def test_scalar_mul_fast_mode_same_group_element(eng, oracle):
+    """ZC_SCALAR_MUL_FAST (windowed, dedicated doubling): NOT limb-exact by design; it must be the
+    same group element as double_and_add -- reference `==` (affine) and identical encodings."""
+    import dusk_zerocaf_amd as z
+    n = 5000
+    P = V.base_multiples(oracle, n, V.SEED + 47)
+    K = V.rand_scalars_np(n, V.SEED + 48, bits=252)
+    _edge_scalars(K)
+    P[9] = V.IDENT_ROW
+    fast = eng.ed_scalar_mul(P, K, flags=z.FAST)
+    want = oracle.ed_scalar_mul(P, K)
+    assert oracle.ed_eq(fast, want).all()
+    assert eq(oracle.ed_compress(fast)[0], oracle.ed_compress(want)[0])
+    assert eq(eng.ris_compress(fast), oracle.ris_compress(want))
+    assert eng.ed_is_valid(fast).all()
+    big = 1 << 18                                                 # and against the strict kernel at size
+    Pb = np.tile(P[:1024], (big >> 10, 1))
+    Kb = V.rand_scalars_np(big, V.SEED + 49, bits=252)
+    assert eng.ed_eq(eng.ed_scalar_mul(Pb, Kb, flags=z.FAST), eng.ed_scalar_mul(Pb, Kb)).all()
+
+
 def test_scalar_mul_full_size_properties(eng, oracle):
     """config 3 at 2^20: linearity (k1+k2)P == k1P + k2P on every element, plus an
     oracle-checked stride sample of exact limbs."""
