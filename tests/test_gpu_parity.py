@@ -346,6 +346,32 @@ def test_ristretto_roundtrip_mul(eng, oracle):
     assert eq(ok, wok) and eq(out, wout) and 0 < (ok == 0).sum() <= len(bad)
 
 
+def test_ristretto_roundtrip_full_size_2_22(eng, oracle):
+    """config 4 at BASELINE size (2^22): composition property on every element --
+    mul(mul(E, k1), k2) == mul(E, k1*k2 mod L) as bytes -- plus an oracle-checked stride sample
+    and ~1% undecodable inputs."""
+    n = 1 << 22
+    small = V.base_multiples(oracle, 1 << 12, V.SEED + 130)
+    enc_small = oracle.ris_compress(small)
+    enc = np.tile(enc_small, (n >> 12, 1))
+    rng = np.random.default_rng(V.SEED + 131)
+    bad = rng.choice(n, size=n // 100, replace=False)
+    enc[bad, :8] ^= rng.integers(1, 256, size=(len(bad), 8), dtype=np.uint8)
+    k1 = V.rand_scalars_np(n, V.SEED + 132, bits=249)
+    k2 = V.rand_scalars_np(n, V.SEED + 133, bits=249)
+    k12 = eng.sc_mul(k1, k2)
+    r1, ok1 = eng.ris_roundtrip_mul(enc, k1)
+    r2, ok2 = eng.ris_roundtrip_mul(r1, k2)
+    r12, ok12 = eng.ris_roundtrip_mul(enc, k12)
+    good = ok1 == 1
+    assert eq(ok12, ok1) and 0 < (~good).sum() <= len(bad)
+    assert ok2[good].all() and eq(r2[good], r12[good])
+    assert not r1[~good].any()
+    idx = np.r_[np.arange(0, n, 8191), bad[:64]]
+    wout, wok = oracle.ris_roundtrip_mul(enc[idx], k1[idx])
+    assert eq(ok1[idx], wok) and eq(r1[idx], wout)
+
+
 def test_next_rows_elligator_validity_projective(eng, oracle, kats):
     """Elligator + from_uniform_bytes, is_valid (Edwards and Ristretto),
     ProjectivePoint add/double -- limb-exact vs the oracle, reference KATs included."""
