@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzerocaf_hip.so")
+# ZC_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("ZC_LIB_PATH") or os.path.join(HERE, "libzerocaf_hip.so")
 
 _u64p = C.c_void_p
 _u8p = C.c_void_p

@@ -8,8 +8,12 @@
 #include <vector>
 #include <string>
 typedef uint32_t u32; typedef uint64_t u64;
+#ifndef CHAINS
 #define CHAINS 8
+#endif
+#ifndef UNROLL
 #define UNROLL 2
+#endif
 
 #define DEF_KERNEL(NAME, DECL, BODY, SINK)                                         \
   extern "C" __global__ __launch_bounds__(256) void NAME(u32* out, int iters, u32 seed) { \
@@ -74,6 +78,12 @@ DEF_KERNEL(k_pk_mul_lo_u16, u32 acc[CHAINS]; for (int c=0;c<CHAINS;c++) acc[c]=c
 DEF_KERNEL(k_pk_mad_u16, u32 acc[CHAINS]; for (int c=0;c<CHAINS;c++) acc[c]=c+a;,
   asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b));, s += acc[c];)
 
+DEF_KERNEL(k_cndmask_sgpr, u32 acc[CHAINS]; for (int c=0;c<CHAINS;c++) acc[c]=c+a; unsigned long long m = __ballot((a & 1) != 0);,
+  asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(acc[c]) : "v"(b), "s"(m));, s += acc[c];)
+DEF_KERNEL(k_bfi_b32, u32 acc[CHAINS]; u32 msk = (a & 1) ? 0xffffffffu : 0u; for (int c=0;c<CHAINS;c++) acc[c]=c+a;,
+  asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(msk), "v"(b));, s += acc[c];)
+DEF_KERNEL(k_cndmask_vcc_set, u32 acc[CHAINS]; for (int c=0;c<CHAINS;c++) acc[c]=c+a; asm volatile("v_cmp_eq_u32 vcc, 1, %0" :: "v"(a & 1) : "vcc");,
+  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc[c]) : "v"(b) : );, s += acc[c];)
 typedef void (*kfn)(u32*, int, u32);
 struct Ent { const char* name; kfn fn; int insts_per_body; };
 
@@ -85,7 +95,8 @@ int main(int argc, char** argv) {
   std::vector<Ent> ents = {
     {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_mad_i64_i32", k_mad_i64_i32, 1}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
     {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 1},
-    {"v_add_u32", k_add_u32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_cndmask_b32", k_cndmask, 1},
+    {"v_add_u32", k_add_u32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr, 1},
+    {"v_cndmask_b32 (vcc set once)", k_cndmask_vcc_set, 1}, {"v_bfi_b32", k_bfi_b32, 1},
     {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_lshrrev_b64", k_lshrrev_b64, 1}, {"v_lshlrev_b64", k_lshlrev_b64, 1},
     {"v_add_co+v_addc (pair)", k_addc_pair, 1}, {"v_mad_u64_u32+v_addc (pair)", k_mad_u64_u32_addc, 1},
     {"v_fma_f64", k_fma_f64, 1}, {"v_add_f64", k_add_f64, 1}, {"v_mul_f64", k_mul_f64, 1}, {"v_fma_f32", k_fma_f32, 1},
