@@ -288,7 +288,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32x9 limbs (radix 2^29, 64-bit accumulators)", "data": "synthetic",
+        "dtype": "u64 (nine 29-bit limbs in u32 registers, 64-bit multiply-accumulate columns)", "data": "synthetic",
         "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random 252-bit scalars (BASELINE configs[2])",
                                 "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
                                 "ristretto": "Ristretto decompress->scalar-mul->compress (BASELINE configs[3] shape)",

@@ -185,3 +185,40 @@ def test_emul_next_rows(emul, oracle, kats):
     assert np.array_equal(o3, oracle.proj_add(A3, B3))
     emul.emul_proj_double(p(A3), p(o3), C.c_size_t(32))
     assert np.array_equal(o3, oracle.proj_double(A3))
+
+
+def test_emul_extreme_operands(emul, oracle):
+    """Worst cases for the lazy-reduction bounds: every limb saturated (2^52 - 1, i.e. the
+    non-canonical value 2^260 - 1), p - 1, p - 2 and 0 in every operand position; the group-law
+    formulas are polynomial identities, so arbitrary (off-curve) coordinates must still match."""
+    sat = [(1 << 52) - 1] * 5
+    pool = [sat, pm.limbs(pm.P - 1), pm.limbs(pm.P - 2), [0] * 5, [1, 0, 0, 0, 0], pm.limbs((pm.P - 1) // 2),
+            pm.limbs(2**252), pm.limbs(pm.P + 5)]
+    a = np.array([x for x in pool for _ in pool], dtype=np.uint64)
+    b = np.array([y for _ in pool for y in pool], dtype=np.uint64)
+    out = np.empty_like(a)
+    emul.emul_fe_mul(p(a), p(b), p(out), C.c_size_t(len(a)), 0)
+    assert np.array_equal(out, oracle.fe_mul(a, b))
+    emul.emul_fe_square(p(a), p(out), C.c_size_t(len(a)), 0)
+    assert np.array_equal(out, oracle.fe_square(a))
+    rng = np.random.default_rng(21)
+    canon = [pm.limbs(pm.P - 1), pm.limbs(pm.P - 2), [0] * 5, [1, 0, 0, 0, 0], pm.limbs((pm.P + 1) // 2)]
+    n = 400
+    P = np.array([sum([canon[rng.integers(len(canon))] if rng.random() < 0.6 else pm.limbs(int(rng.integers(0, 2**62)) * 2**190 % pm.P)
+                       for _ in range(4)], []) for _ in range(n)], dtype=np.uint64)
+    Q = P[rng.permutation(n)]
+    o = np.empty_like(P)
+    emul.emul_ed_add(p(P), p(Q), p(o), C.c_size_t(n))
+    assert np.array_equal(o, oracle.ed_add(P, Q))
+    emul.emul_ed_sub(p(P), p(Q), p(o), C.c_size_t(n))
+    assert np.array_equal(o, oracle.ed_sub(P, Q))
+    K = np.zeros((n, 5), dtype=np.uint64)                        # short scalars: chained adds of extremes
+    K[:, 0] = rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+    emul.emul_ed_scalar_mul(p(P), p(K), p(o), C.c_size_t(n))
+    assert np.array_equal(o, oracle.ed_scalar_mul(P, K))
+    A3, B3 = np.ascontiguousarray(P[:, :15]), np.ascontiguousarray(Q[:, :15])
+    o3 = np.empty_like(A3)
+    emul.emul_proj_add(p(A3), p(B3), p(o3), C.c_size_t(n))
+    assert np.array_equal(o3, oracle.proj_add(A3, B3))
+    emul.emul_proj_double(p(A3), p(o3), C.c_size_t(n))
+    assert np.array_equal(o3, oracle.proj_double(A3))

@@ -210,6 +210,31 @@ def test_point_ops_bulk(eng, oracle, n):
     assert eq(eng.ed_mul_by_pow_2(P, 5), oracle.ed_mul_by_pow_2(P, 5))
 
 
+def test_extreme_operands(eng, oracle):
+    """Saturated limbs / p-1 / 0 in every position (worst cases of the lazy-reduction bounds) and
+    off-curve coordinates through the group-law kernels: polynomial identities must still hold."""
+    sat = [(1 << 52) - 1] * 5
+    pool = [sat, pm.limbs(pm.P - 1), pm.limbs(pm.P - 2), [0] * 5, [1, 0, 0, 0, 0], pm.limbs((pm.P - 1) // 2),
+            pm.limbs(2**252), pm.limbs(pm.P + 5)]
+    a = np.array([x for x in pool for _ in pool], dtype=np.uint64)
+    b = np.array([y for _ in pool for y in pool], dtype=np.uint64)
+    assert eq(eng.fe_mul(a, b), oracle.fe_mul(a, b)) and eq(eng.fe_square(a), oracle.fe_square(a))
+    assert eq(eng.fe_add(a, b), oracle.fe_add(a, b)) and eq(eng.fe_sub(a, b), oracle.fe_sub(a, b))   # incidental cases too
+    rng = np.random.default_rng(21)
+    canon = [pm.limbs(pm.P - 1), pm.limbs(pm.P - 2), [0] * 5, [1, 0, 0, 0, 0], pm.limbs((pm.P + 1) // 2)]
+    n = 600
+    P = np.array([sum([canon[rng.integers(len(canon))] if rng.random() < 0.6 else pm.limbs(int(rng.integers(0, 2**62)) * 2**190 % pm.P)
+                       for _ in range(4)], []) for _ in range(n)], dtype=np.uint64)
+    Q = P[rng.permutation(n)]
+    assert eq(eng.ed_add(P, Q), oracle.ed_add(P, Q)) and eq(eng.ed_sub(P, Q), oracle.ed_sub(P, Q))
+    assert eq(eng.ed_double(P), oracle.ed_double(P))
+    K = np.zeros((n, 5), dtype=np.uint64)
+    K[:, 0] = rng.integers(0, 1 << 50, size=n, dtype=np.uint64)
+    assert eq(eng.ed_scalar_mul(P, K), oracle.ed_scalar_mul(P, K))
+    A3, B3 = np.ascontiguousarray(P[:, :15]), np.ascontiguousarray(Q[:, :15])
+    assert eq(eng.proj_add(A3, B3), oracle.proj_add(A3, B3)) and eq(eng.proj_double(A3), oracle.proj_double(A3))
+
+
 def _edge_scalars(K):
     K[0] = 0
     if len(K) > 8:
