@@ -25,6 +25,12 @@ SIGNATURES = {
     "zc_fe_mul": [_u64p, _u64p, _u64p, _n],
     "zc_fe_square": [_u64p, _u64p, _n],
     "zc_fe_invert": [_u64p, _u64p, _u8p, _n],
+    "zc_fe_div": [_u64p, _u64p, _u64p, _u8p, _n],
+    "zc_fe_half": [_u64p, _u64p, _n],
+    "zc_fe_pow": [_u64p, _u64p, _u64p, _n],
+    "zc_fe_legendre_symbol": [_u64p, _u8p, _n],
+    "zc_fe_is_positive": [_u64p, _u8p, _n],
+    "zc_fe_mod_sqrt": [_u64p, C.c_int, _u64p, _u8p, _n],
     "zc_fe_from_bytes": [_u8p, _u64p, _n],
     "zc_fe_to_bytes": [_u64p, _u8p, _n],
     "zc_fe_sqrt_ratio_i": [_u64p, _u64p, _u64p, _u8p, _n],

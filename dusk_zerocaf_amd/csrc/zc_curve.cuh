@@ -148,6 +148,29 @@ ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t
     }
 }
 
+// a^e for a per-lane exponent e given as plain canonical limbs (Pow, field.rs:325-355):
+// fixed 253-step left-to-right ladder with a selected multiply, same value as the reference's
+// data-dependent loop.  a R-class Montgomery, e as nine 29-bit plain limbs.
+ZC_DI fe fp_pow_var(const fe& a, const fe& e)
+{
+    fe acc = fe_one_m<FP>();
+    for (int i = 260; i >= 0; i--) {
+        acc = fp_sqr(acc);
+        const bool bit = ((e.v[i / 29] >> (i % 29)) & 1) != 0;
+        acc = fe_select(bit, fp_mul(acc, a), acc);
+    }
+    return acc;
+}
+// legendre_symbol (field.rs:703-706): Choice(0) iff a^((p-1)/2) == -1 (so 0 maps to 1)
+ZC_DI bool fp_legendre(const fe& a)
+{
+    const fe w = fp_pow(a, ZC_EXP_P58, ModP::EXP_P58_BITS);      // a^((q-1)/2)
+    const fe t = fp_mul(fp_mul(a, w), w);                         // a^q
+    fe one = fe_zero();
+    one.v[0] = 1;
+    return !fe_eq_canon(fp_canon(fp_sqr(t)), fe_n_minus_canon<FP>(one));
+}
+
 // ---------------------------------------------------------------- points
 ZC_DI pt pt_identity()                                            // edwards.rs:381-391
 {

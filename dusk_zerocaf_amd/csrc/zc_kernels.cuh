@@ -210,6 +210,63 @@ ZC_KERNEL void k_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* 
     if (was_square) was_square[i] = sq ? 1 : 0;
 }
 
+// F8/F9 rows: Div, Half, Pow, legendre_symbol, ModSqrt, is_positive
+ZC_KERNEL void k_fe_div(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n)   // field.rs:277-300
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const fe x = fe_load_mont<FP>(a + 5 * i), y = fe_load_mont<FP>(b + 5 * i);
+    const bool nz = !fp_is_zero(y);
+    fe_store_canon<FP>(out + 5 * i, fp_mul(x, fp_invert(y)));
+    if (ok) ok[i] = nz ? 1 : 0;
+}
+ZC_KERNEL void k_fe_half(const u64* a, u64* out, size_t n)                          // field.rs:317-323
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5], h[5];
+    load5(l, a + 5 * i);
+    fe_to_limbs52(h, fe_n_minus_canon<FP>(fe_const<FP>(ModP::HALF)));             // (p+1)/2 = p - (p-1)/2
+    const fe p2 = mont_mul<FP>(mont_to<FP>(fe_from_limbs52(l)), fe_from_limbs52(h));
+    fe_to_limbs52(h, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(p2)));
+    store5(out + 5 * i, h);
+}
+ZC_KERNEL void k_fe_pow(const u64* a, const u64* e, u64* out, size_t n)            // field.rs:325-355
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5];
+    load5(l, e + 5 * i);
+    fe_store_canon<FP>(out + 5 * i, fp_pow_var(fe_load_mont<FP>(a + 5 * i), fe_from_limbs52(l)));
+}
+ZC_KERNEL void k_fe_legendre(const u64* a, uint8_t* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    out[i] = fp_legendre(fe_load_mont<FP>(a + 5 * i)) ? 1 : 0;
+}
+ZC_KERNEL void k_fe_is_positive(const u64* a, uint8_t* out, size_t n)              // field.rs:552-557 (limb-lexicographic)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5], h[5];
+    load5(l, a + 5 * i);
+    fe_to_limbs52(h, fe_const<FP>(ModP::HALF));
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) c = (l[j] > h[j]) ? 1 : ((l[j] < h[j]) ? -1 : c);
+    out[i] = (c <= 0) ? 1 : 0;
+}
+ZC_KERNEL void k_fe_mod_sqrt(const u64* a, int sign, u64* out, uint8_t* ok, size_t n)   // field.rs:357-441
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    fe x;
+    const bool have = fp_mod_sqrt(x, fe_load_mont<FP>(a + 5 * i), sign != 0);
+    fe_store_canon<FP>(out + 5 * i, fe_select(have, x, fe_zero()));
+    if (ok) ok[i] = have ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ byte codecs
 ZC_DI void load_words256(u64 (&w)[4], const uint8_t* __restrict__ p)
 {

@@ -504,6 +504,34 @@ int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, siz
         }
     });
 }
+int zc_fe_div(zc_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n)
+{
+    REQUIRE(a); REQUIRE(b); REQUIRE(out);
+    Arg args[4] = {in_arg(a, 40), in_arg(b, 40), out_arg(out, 40), out_arg(ok, 1)};
+    return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_fe_div, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
+    });
+}
+int zc_fe_half(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_half, a, o, n, 40); }
+int zc_fe_pow(zc_ctx* c, const uint64_t* a, const uint64_t* e, uint64_t* o, size_t n) { return binop(c, zc::k_fe_pow, nullptr, a, e, o, n, 40); }
+static int fe_flag_op(zc_ctx* ctx, void (*k)(const u64*, uint8_t*, size_t), const uint64_t* a, uint8_t* out, size_t n)
+{
+    REQUIRE(a); REQUIRE(out);
+    Arg args[2] = {in_arg(a, 40), out_arg(out, 1)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_fe_legendre_symbol(zc_ctx* c, const uint64_t* a, uint8_t* o, size_t n) { return fe_flag_op(c, zc::k_fe_legendre, a, o, n); }
+int zc_fe_is_positive(zc_ctx* c, const uint64_t* a, uint8_t* o, size_t n) { return fe_flag_op(c, zc::k_fe_is_positive, a, o, n); }
+int zc_fe_mod_sqrt(zc_ctx* ctx, const uint64_t* a, int sign, uint64_t* out, uint8_t* ok, size_t n)
+{
+    REQUIRE(a); REQUIRE(out);
+    Arg args[3] = {in_arg(a, 40), out_arg(out, 40), out_arg(ok, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_fe_mod_sqrt, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], sign, (u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
 int zc_fe_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);

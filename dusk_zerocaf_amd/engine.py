@@ -114,6 +114,33 @@ class Engine:
         self._call("zc_fe_invert", pa, po, pk, n)
         return out, ok
 
+    def fe_div(self, a, b):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        b, pb, _ = self._prep(b, 5, np.uint64)
+        out, po = self._alloc(a, n, 5, np.uint64)
+        ok, pk = self._alloc(a, n, 0, np.uint8)
+        self._call("zc_fe_div", pa, pb, po, pk, n)
+        return out, ok
+
+    def fe_half(self, a): return self._un("zc_fe_half", a, 5)
+    def fe_pow(self, a, e): return self._bin("zc_fe_pow", a, e, 5)
+
+    def _fe_flag(self, name, a):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 0, np.uint8)
+        self._call(name, pa, po, n)
+        return out
+
+    def fe_legendre_symbol(self, a): return self._fe_flag("zc_fe_legendre_symbol", a)
+    def fe_is_positive(self, a): return self._fe_flag("zc_fe_is_positive", a)
+
+    def fe_mod_sqrt(self, a, sign):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 5, np.uint64)
+        ok, pk = self._alloc(a, n, 0, np.uint8)
+        self._call("zc_fe_mod_sqrt", pa, C.c_int(int(sign)), po, pk, n)
+        return out, ok
+
     def fe_from_bytes(self, b):
         b, pb, n = self._prep(b, 32, np.uint8)
         out, po = self._alloc_u64(b, n, 5)

@@ -88,6 +88,15 @@ int zc_fe_mul(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, 
 int zc_fe_square(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 /* inverse: field.rs:854-925 (panics on 0 -> ok[i] = 0, out = 0) */
 int zc_fe_invert(zc_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *ok, size_t n);
+/* Div: field.rs:277-300 (divide by 0 asserts -> ok = 0)   Half: :317-323   Pow: :325-355 (e: canonical limbs) */
+int zc_fe_div(zc_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *ok, size_t n);
+int zc_fe_half(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int zc_fe_pow(zc_ctx *ctx, const uint64_t *a, const uint64_t *e, uint64_t *out, size_t n);
+/* legendre_symbol: field.rs:703-706 (Choice: 1 = residue, also for 0)   is_positive: :552-557 */
+int zc_fe_legendre_symbol(zc_ctx *ctx, const uint64_t *a, uint8_t *out, size_t n);
+int zc_fe_is_positive(zc_ctx *ctx, const uint64_t *a, uint8_t *out, size_t n);
+/* ModSqrt (Tonelli-Shanks value): field.rs:357-441; sign = Choice (1 selects p - x); None -> ok = 0 */
+int zc_fe_mod_sqrt(zc_ctx *ctx, const uint64_t *a, int sign, uint64_t *out, uint8_t *ok, size_t n);
 /* from_bytes: field.rs:563-587   to_bytes: :591-631 */
 int zc_fe_from_bytes(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, size_t n);
 int zc_fe_to_bytes(zc_ctx *ctx, const uint64_t *in, uint8_t *out32, size_t n);

@@ -1074,6 +1074,16 @@ void zr_fe_invert_batch(const uint64_t *a, uint64_t *out, uint8_t *ok, size_t n)
         if (ok) ok[i] = (uint8_t)o;
     }
 }
+void zr_fe_div_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *ok, size_t n)
+{ for (size_t i = 0; i < n; i++) { zr_fe r; int o = zr_fe_div(&r, FE(a, i), FE(b, i)); *FEO(out, i) = r; if (ok) ok[i] = (uint8_t)o; } }
+BINOP_BATCH(zr_fe_pow_batch, zr_fe_pow)
+UNOP_BATCH(zr_fe_half_batch, zr_fe_half)
+void zr_fe_legendre_symbol_batch(const uint64_t *a, uint8_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) out[i] = (uint8_t)zr_fe_legendre_symbol(FE(a, i)); }
+void zr_fe_is_positive_batch(const uint64_t *a, uint8_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) out[i] = (uint8_t)zr_fe_is_positive(FE(a, i)); }
+void zr_fe_mod_sqrt_batch(const uint64_t *a, int sign, uint64_t *out, uint8_t *ok, size_t n)
+{ for (size_t i = 0; i < n; i++) { zr_fe r; int o = zr_fe_mod_sqrt(&r, FE(a, i), sign); *FEO(out, i) = r; if (ok) ok[i] = (uint8_t)o; } }
 void zr_fe_from_bytes_batch(const uint8_t *in, uint64_t *out, size_t n)
 { for (size_t i = 0; i < n; i++) zr_fe_from_bytes(FEO(out, i), in + 32 * i); }
 void zr_fe_to_bytes_batch(const uint64_t *in, uint8_t *out, size_t n)

@@ -115,6 +115,12 @@ void zr_fe_mul_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t
 void zr_fe_neg_batch(const uint64_t *a, uint64_t *out, size_t n);
 void zr_fe_square_batch(const uint64_t *a, uint64_t *out, size_t n);
 void zr_fe_invert_batch(const uint64_t *a, uint64_t *out, uint8_t *ok, size_t n);
+void zr_fe_div_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *ok, size_t n);
+void zr_fe_pow_batch(const uint64_t *a, const uint64_t *e, uint64_t *out, size_t n);
+void zr_fe_half_batch(const uint64_t *a, uint64_t *out, size_t n);
+void zr_fe_legendre_symbol_batch(const uint64_t *a, uint8_t *out, size_t n);
+void zr_fe_is_positive_batch(const uint64_t *a, uint8_t *out, size_t n);
+void zr_fe_mod_sqrt_batch(const uint64_t *a, int sign, uint64_t *out, uint8_t *ok, size_t n);
 void zr_fe_from_bytes_batch(const uint8_t *in, uint64_t *out, size_t n);
 void zr_fe_to_bytes_batch(const uint64_t *in, uint8_t *out, size_t n);
 void zr_fe_sqrt_ratio_i_batch(const uint64_t *u, const uint64_t *v, uint64_t *out, uint8_t *was_square, size_t n);

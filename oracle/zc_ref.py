@@ -85,6 +85,39 @@ ed_double = _unop("zr_ed_double_batch", 20)
 ed_neg = _unop("zr_ed_neg_batch", 20)
 
 
+fe_pow = _binop("zr_fe_pow_batch", 5)
+fe_half = _unop("zr_fe_half_batch", 5)
+
+
+def fe_div(a, b):
+    a, b = _u64(a, 5), _u64(b, 5)
+    out = np.empty_like(a)
+    ok = np.empty(a.shape[0], dtype=np.uint8)
+    lib().zr_fe_div_batch(_p(a), _p(b), _p(out), _p(ok), C.c_size_t(a.shape[0]))
+    return out, ok
+
+
+def _fe_flag(name):
+    def f(a):
+        a = _u64(a, 5)
+        out = np.empty(a.shape[0], dtype=np.uint8)
+        getattr(lib(), name)(_p(a), _p(out), C.c_size_t(a.shape[0]))
+        return out
+    return f
+
+
+fe_legendre_symbol = _fe_flag("zr_fe_legendre_symbol_batch")
+fe_is_positive = _fe_flag("zr_fe_is_positive_batch")
+
+
+def fe_mod_sqrt(a, sign):
+    a = _u64(a, 5)
+    out = np.empty_like(a)
+    ok = np.empty(a.shape[0], dtype=np.uint8)
+    lib().zr_fe_mod_sqrt_batch(_p(a), C.c_int(sign), _p(out), _p(ok), C.c_size_t(a.shape[0]))
+    return out, ok
+
+
 def fe_invert(a):
     a = _u64(a, 5)
     out = np.empty_like(a)

@@ -179,6 +179,44 @@ def test_sqrt_ratio_bulk(eng, oracle):
     assert eq(sq, wsq) and eq(out, want) and 0 < sq.sum() < n
 
 
+def test_field_f8_rows(eng, oracle, kats):
+    """F7/F8/F9 leftovers: Div, Half, Pow, legendre_symbol, ModSqrt (both signs), is_positive --
+    reference KATs (division, a_pow_b, legendre_symbol, mod_sqrt_tonelli_shanks) and bulk parity."""
+    f = lambda n: np.array([kats["field"][n]["limbs"]], dtype=np.uint64)
+    a, b, exp = [np.array([x["limbs"]], dtype=np.uint64) for x in kats["field_division"]]
+    q, ok = eng.fe_div(eng.fe_neg(a), b)
+    assert ok[0] == 1 and eq(q, exp)                               # division
+    assert eng.fe_div(a, np.zeros((1, 5), dtype=np.uint64))[1][0] == 0
+    assert eq(eng.fe_pow(f("A"), f("C")), f("A_POW_C")) and eq(eng.fe_pow(f("A"), f("B")), f("A_POW_B"))   # a_pow_b
+    sev = np.array([[17, 0, 0, 0, 0]], dtype=np.uint64)
+    assert eng.fe_legendre_symbol(f("A"))[0] == 0 and eng.fe_legendre_symbol(sev)[0] == 1                  # legendre_symbol
+    r0, ok0 = eng.fe_mod_sqrt(sev, 0)
+    r1, ok1 = eng.fe_mod_sqrt(sev, 1)
+    assert ok0[0] == 1 and ok1[0] == 1 and eq(r0, f("SQRT1_27_NEG")) and eq(r1, f("SQRT1_27_POS"))         # mod_sqrt_tonelli_shanks
+    assert eng.fe_mod_sqrt(f("A"), 0)[1][0] == 0                                                           # non_QRmod_sqrt
+    assert eq(eng.fe_half(f("A_MINUS_B")), f("A_MINUS_B_HALF"))
+    n = 3000
+    x, y = V.rand_fe_np(n, V.SEED + 140), V.rand_fe_np(n, V.SEED + 141)
+    x[0] = 0
+    y[1] = 0
+    got, ok = eng.fe_div(x, y)
+    want, wok = oracle.fe_div(x, y)
+    assert eq(ok, wok) and eq(got, want)
+    assert eq(eng.fe_half(x), oracle.fe_half(x))
+    assert eq(eng.fe_legendre_symbol(x), oracle.fe_legendre_symbol(x))
+    assert eq(eng.fe_is_positive(x), oracle.fe_is_positive(x))
+    raw = np.random.default_rng(V.SEED + 142).integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)       # non-canonical limbs too
+    assert eq(eng.fe_is_positive(raw), oracle.fe_is_positive(raw))
+    for sign in (0, 1):
+        got, ok = eng.fe_mod_sqrt(x, sign)
+        want, wok = oracle.fe_mod_sqrt(x, sign)
+        assert eq(ok, wok) and eq(got, want) and 0 < ok.sum() < n
+    e = V.rand_fe_np(300, V.SEED + 143)
+    e[0] = 0
+    e[1] = [1, 0, 0, 0, 0]
+    assert eq(eng.fe_pow(x[:300], e), oracle.fe_pow(x[:300], e))
+
+
 def test_bytes_codecs_bulk(eng, oracle):
     rng = np.random.default_rng(V.SEED + 26)
     raw = rng.integers(0, 256, size=(5000, 32), dtype=np.uint8)
