@@ -73,6 +73,27 @@ struct FieldElement {
         if (b == zero()) throw std::domain_error("Cannot divide by zero.");   // field.rs:285
         return *this * b.inverse();
     }
+    FieldElement half() const { FieldElement r; Backend::check(zc_fe_half(Backend::ctx(), l.data(), r.l.data(), 1), "zc_fe_half"); return r; }   // Half, field.rs:317-323
+    FieldElement pow(const FieldElement& e) const                                       // Pow, field.rs:325-355
+    {
+        FieldElement r;
+        Backend::check(zc_fe_pow(Backend::ctx(), l.data(), e.l.data(), r.l.data(), 1), "zc_fe_pow");
+        return r;
+    }
+    bool legendre_symbol() const                                                        // field.rs:703-706
+    {
+        uint8_t c = 0;
+        Backend::check(zc_fe_legendre_symbol(Backend::ctx(), l.data(), &c, 1), "zc_fe_legendre_symbol");
+        return c != 0;
+    }
+    bool is_positive() const                                                            // field.rs:552-557
+    {
+        uint8_t c = 0;
+        Backend::check(zc_fe_is_positive(Backend::ctx(), l.data(), &c, 1), "zc_fe_is_positive");
+        return c != 0;
+    }
+    bool is_even() const { return (l[0] & 1) == 0; }                                    // field.rs:534-539
+    std::optional<FieldElement> mod_sqrt(bool sign) const;                              // ModSqrt, field.rs:357-441
     // (Choice, FieldElement), field.rs:462-503
     std::pair<bool, FieldElement> sqrt_ratio_i(const FieldElement& v) const
     {
@@ -99,6 +120,15 @@ struct FieldElement {
     uint64_t operator[](size_t i) const { return l[i]; }
 };
 
+inline std::optional<FieldElement> FieldElement::mod_sqrt(bool sign) const
+{
+    FieldElement r;
+    uint8_t ok = 0;
+    Backend::check(zc_fe_mod_sqrt(Backend::ctx(), l.data(), sign ? 1 : 0, r.l.data(), &ok, 1), "zc_fe_mod_sqrt");
+    if (!ok) return std::nullopt;
+    return r;
+}
+
 struct Scalar {
     std::array<uint64_t, 5> l{};
     Scalar() = default;
@@ -120,6 +150,17 @@ struct Scalar {
     Scalar operator-() const { Scalar r; Backend::check(zc_sc_neg(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_neg"); return r; }
     Scalar square() const { Scalar r; Backend::check(zc_sc_square(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_square"); return r; }
     bool is_even() const { return (l[0] & 1) == 0; }                         // scalar.rs:346-348
+    Scalar half_without_mod() const                                         // scalar.rs:562-574
+    {
+        Scalar r = *this;
+        uint64_t carry = 0;
+        for (int i = 4; i >= 0; i--) {
+            r.l[i] |= carry;
+            carry = (r.l[i] & 1) << 52;
+            r.l[i] >>= 1;
+        }
+        return r;
+    }
     static Scalar from_bytes(const std::array<uint8_t, 32>& b)
     {
         Scalar r;

@@ -43,6 +43,12 @@ int main()
     CHECK((-FieldElement(126296) / FieldElement(126297)) == constants::EDWARDS_D());                       // doc-test src/field.rs:51
     CHECK(-(FieldElement(27).inv_sqrt().second) ==
           FieldElement(L5{2352169988867884ull, 2446401460527425ull, 986927416739735ull, 989222758354178ull, 11393383279360ull})); // inv_sqrt
+    CHECK(A.pow(C) == FieldElement(L5{2259014482295528ull, 2217393058433059ull, 1440043558784742ull, 1085733660253890ull, 11974469306680ull})); // a_pow_b
+    CHECK(!A.legendre_symbol() && FieldElement(17).legendre_symbol());                                      // legendre_symbol
+    CHECK(FieldElement(17).mod_sqrt(false).has_value() &&
+          FieldElement(17).mod_sqrt(false)->l == L5{933733106825591ull, 3470287880816342ull, 2891894702196915ull, 3836949834964192ull, 14650685232542ull}); // mod_sqrt_tonelli_shanks
+    CHECK(!A.mod_sqrt(false).has_value() && !A.mod_sqrt(true).has_value());                                 // non_QRmod_sqrt
+    CHECK(A.is_even() && !B.is_even());                                                                     // evenness
     const std::array<uint8_t, 32> m1b = {236, 211, 245, 92, 26, 99, 18, 88, 214, 156, 247, 162, 222, 249, 222, 20, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16};
     CHECK(FieldElement::from_bytes(m1b).l == FieldElement::minus_one().l && FieldElement::minus_one().to_bytes() == m1b);
 
@@ -53,6 +59,7 @@ int main()
     CHECK(Y.square().l == L5{3511508334592158ull, 913859277470939ull, 3383393792942685ull, 3918279098243301ull, 1168230887094ull});
     CHECK((Y * Scalar::one()).l == Y.l && (Y * Scalar::zero()).l == Scalar::zero().l);
     CHECK(Scalar::two_pow_k(249).l == L5{0, 0, 0, 0, 2199023255552ull});
+    CHECK(Scalar(L5{0, 1, 0, 0, 0}).half_without_mod().l == L5{2251799813685248ull, 0, 0, 0, 0});
     threw = false;
     try { (void)Scalar::two_pow_k(250); } catch (const std::domain_error&) { threw = true; }
     CHECK(threw);
