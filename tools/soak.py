@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Randomised soak: large seeded batches through the HIP engine vs the CPU oracle (threads).
+Not part of the test suite; run on the GPU box for extra confidence."""
+import concurrent.futures as cf
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dusk_zerocaf_amd as z
+from oracle import zc_ref, pymodel as pm
+from tests import vectors as V
+
+def par(fn, n, *arrs):
+    th = min(16, os.cpu_count() or 1)
+    idx = np.array_split(np.arange(n), th)
+    with cf.ThreadPoolExecutor(th) as ex:
+        parts = list(ex.map(lambda ix: fn(*[a[ix] for a in arrs]), idx))
+    if isinstance(parts[0], tuple):
+        return tuple(np.concatenate([p[j] for p in parts]) for j in range(len(parts[0])))
+    return np.concatenate(parts)
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+eng = z.Engine()
+zc_ref.build()
+t0 = time.time()
+n = 1 << 16
+base = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (n, 1))
+P = eng.ed_scalar_mul(base, V.rand_scalars_np(n, seed * 100 + 1, bits=249))
+for bits in (249, 252):
+    K = V.rand_scalars_np(n, seed * 100 + bits, bits=bits)
+    got = eng.ed_scalar_mul(P, K)
+    want = par(zc_ref.ed_scalar_mul, n, P, K)
+    assert np.array_equal(got, want), "scalar_mul bits=%d" % bits
+    enc = eng.ris_compress(got)
+    assert np.array_equal(enc, par(zc_ref.ris_compress, n, got)), "ris_compress"
+    out, ok = eng.ris_roundtrip_mul(enc, K)
+    wout, wok = par(zc_ref.ris_roundtrip_mul, n, enc, K)
+    assert np.array_equal(out, wout) and np.array_equal(ok, wok), "roundtrip"
+    ec, eok = eng.ed_compress(got)
+    wec, weok = par(zc_ref.ed_compress, n, got)
+    assert np.array_equal(ec, wec) and np.array_equal(eok, weok), "ed_compress"
+    dd, dok = eng.ed_decompress(ec)
+    wdd, wdok = par(zc_ref.ed_decompress, n, ec)
+    assert np.array_equal(dd, wdd) and np.array_equal(dok, wdok), "ed_decompress"
+m = 1 << 21
+a, b = V.rand_fe_np(m, seed * 100 + 7), V.rand_fe_np(m, seed * 100 + 8)
+assert np.array_equal(eng.fe_mul(a, b), par(zc_ref.fe_mul, m, a, b))
+assert np.array_equal(eng.fe_square(a), par(zc_ref.fe_square, m, a))
+sa, sb = V.rand_fe_np(m, seed * 100 + 9, pm.L), V.rand_fe_np(m, seed * 100 + 10, pm.L)
+assert np.array_equal(eng.sc_mul(sa, sb), par(zc_ref.sc_mul, m, sa, sb))
+inv, ok = eng.fe_invert(a[: 1 << 18])
+winv, wok = par(zc_ref.fe_invert, 1 << 18, a[: 1 << 18])
+assert np.array_equal(inv, winv) and np.array_equal(ok, wok)
+rng = np.random.default_rng(seed)
+raw = rng.integers(0, 256, size=(1 << 15, 32), dtype=np.uint8); raw[:, 31] &= 0x1F
+d, ok = eng.ris_decompress(raw); wd, wok = par(zc_ref.ris_decompress, len(raw), raw)
+assert np.array_equal(d, wd) and np.array_equal(ok, wok)
+print("soak seed %d ok in %.1f s" % (seed, time.time() - t0))
