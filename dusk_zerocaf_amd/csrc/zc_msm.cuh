@@ -31,6 +31,25 @@ ZC_DI u32 scalar_digit(const u64 (&l)[5], int w, int c)
     return (u32)x & ((1u << c) - 1);
 }
 
+// largest scalar bit length of the shard (wave reduce, one atomicMax per wave): windows above it
+// hold only zero digits and are not generated at all
+ZC_KERNEL void k_msm_maxbits(const u64* k, int* maxbits, size_t n)
+{
+    const size_t i = gid();
+    int bits = 0;
+    if (i < n) {
+        u64 l[5];
+        load5(l, k + 5 * i);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const u64 x = l[j] & M52;
+            if (x) bits = 52 * j + (64 - __builtin_clzll(x));
+        }
+    }
+    bits = wave_max_i32(bits);
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(maxbits, bits);
+}
+
 ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c, int W)
 {
     const size_t i = gid();

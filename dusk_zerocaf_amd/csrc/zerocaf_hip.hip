@@ -306,7 +306,26 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     c -= 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
-    const int W = (260 + c - 1) / c;
+    // number of windows from the longest scalar actually present (canonical scalars: 250-253 bits)
+    int maxbits = 0;
+    {
+        int rc = ensure(&D.tmp[1], &D.tmp_bytes[1], 256);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(D.tmp[1], 0, sizeof(int), D.s()));
+        hipLaunchKernelGGL(zc::k_msm_maxbits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, (int*)D.tmp[1], cnt);
+        HIP_TRY(hipMemcpyAsync(&maxbits, D.tmp[1], sizeof(int), hipMemcpyDeviceToHost, D.s()));
+        HIP_TRY(hipStreamSynchronize(D.s()));
+    }
+    if (maxbits == 0) {                                   // all scalars zero: the sum is the identity
+        static const uint64_t ident[20] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int rc = ensure(&D.tmp[0], &D.tmp_bytes[0], 256);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(D.tmp[0], ident, sizeof ident, hipMemcpyHostToDevice, D.s()));
+        HIP_TRY(hipStreamSynchronize(D.s()));
+        *result = (const u64*)D.tmp[0];
+        return ZC_OK;
+    }
+    const int W = (maxbits + c - 1) / c;
     const size_t m = cnt * (size_t)W;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
     const size_t nb = (size_t)W << c;                     // buckets

@@ -483,6 +483,17 @@ def test_msm_small(eng, oracle):
         assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
 
 
+def test_msm_degenerate_scalars(eng, oracle):
+    n = 6000
+    P = V.base_multiples(oracle, 1024, V.SEED + 86)
+    P = np.tile(P, (6, 1))[:n].copy()
+    ident = np.array([V.IDENT_ROW], dtype=np.uint64)
+    assert oracle.ed_eq(eng.msm(P, np.zeros((n, 5), dtype=np.uint64)), ident)[0] == 1       # all-zero scalars
+    K = np.zeros((n, 5), dtype=np.uint64)
+    K[:, 0] = np.arange(n) % 7                                                               # 3-bit scalars: one window
+    assert eq(oracle.ed_compress(eng.msm(P, K))[0], oracle.ed_compress(_gpu_naive_msm(eng, P, K))[0])
+
+
 def _gpu_naive_msm(eng, P, K):
     """sum_i k_i P_i through separately-tested kernels: batched scalar-mul, then pairwise adds."""
     q = eng.ed_scalar_mul(P, K)
