@@ -63,6 +63,8 @@ SIGNATURES = {
     "zc_proj_add": [_u64p, _u64p, _u64p, _n],
     "zc_proj_double": [_u64p, _u64p, _n],
     "zc_proj_to_extended": [_u64p, _u64p, _n],
+    "zc_ed_mul_base": [_u64p, _u64p, _n],
+    "zc_ris_mul_base_compress": [_u64p, _u8p, _n],
     "zc_msm": [_u64p, _u64p, _n, _u64p],
 }
 CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_set_stream", "zc_ctx_synchronize",

@@ -10,6 +10,15 @@ namespace zc {
 constexpr int ZC_BLOCK = 256;
 
 ZC_DI size_t gid() { return (size_t)blockIdx.x * ZC_BLOCK + threadIdx.x; }
+ZC_DI int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int u = __shfl_xor(v, o);
+        v = u > v ? u : v;
+    }
+    return v;
+}
 
 // ------------------------------------------------------------------ radix-2^52 add/sub
 // Add/Sub/Neg are carry/borrow chains over the reference's own limbs
@@ -509,15 +518,6 @@ ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64*
 // line per entry).  ~0.63x the multiplier work of the reference's formula sequence and no SIMT
 // divergence at all.  The result is the same group element as double_and_add's (identical
 // encodings); only its projective (X:Y:Z:T) representative differs.
-ZC_DI int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int u = __shfl_xor(v, o);
-        v = u > v ? u : v;
-    }
-    return v;
-}
 ZC_KERNEL void k_ed_scalar_mul_fast(const u64* p, const u64* k, size_t k_stride, u64* out, u32* table, size_t n)
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
@@ -558,6 +558,82 @@ ZC_KERNEL void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t
         store_words256(out + 32 * i, w);
         if (ok) ok[i] = dec ? 1 : 0;
     }
+}
+
+// ---- fixed-base multiplication of the curve basepoint ------------------------
+// The reference's only fixed-base routine, window_naf_mul (edwards.rs:155-171), mis-indexes its
+// odd-multiples table and its test is commented out; the key-generation half of its ECDH bench
+// therefore uses the variable-base algorithms on BASEPOINT.  This is the correct fixed-base
+// counterpart: a comb table T[w][j] = (j+1) * 16^w * B (66 windows x 8 cached points, 66 KB,
+// L2-resident) and k*B = sum_w sign(d_w) * T[w][|d_w| - 1] over the signed radix-16 digits --
+// 66 cached additions, no doublings.  Equal to `&BASEPOINT * &k` as a group element; the fused
+// variant emits Ristretto encodings, which are bit-identical to the reference's.
+constexpr int ZC_BASE_WINDOWS = 66;
+
+// lane j (0..7) builds the column (j+1) * 16^w * B for w = 0..65
+ZC_KERNEL void k_base_table_build(u32* table)
+{
+    const int j = threadIdx.x;
+    if (j >= 8) return;
+    pt B;
+    B.X = fe_const<FP>(ModP::BASE_X_M);
+    B.Y = fe_const<FP>(ModP::BASE_Y_M);
+    B.Z = fe_one_m<FP>();
+    B.T = fe_const<FP>(ModP::BASE_T_M);
+    pt P = B;
+    for (int a = 0; a < 7; a++) {
+        const pt s = pt_add(P, B);
+        P = pt_select(a < j, s, P);                       // P = (j+1) * B
+    }
+    for (int w = 0; w < ZC_BASE_WINDOWS; w++) {
+        niels_store(table + 32 * (w * 8 + j), niels_from_pt(P));
+        P = pt_add(P, P);
+        P = pt_add(P, P);
+        P = pt_add(P, P);
+        P = pt_add(P, P);
+    }
+}
+ZC_DI pt base_mul(const u32* __restrict__ table, const int8_t* __restrict__ dig, int stride, int top)
+{
+    pt Q = pt_identity();
+    for (int w = top; w >= 0; w--) {
+        const int d = dig[w * stride];
+        const int mag = d < 0 ? -d : d;
+        niels c = niels_identity();
+        if (mag != 0) c = niels_load(table + 32 * (w * 8 + mag - 1));
+        Q = pt_add_cached(Q, niels_cond_neg(d < 0, c));
+    }
+    return Q;
+}
+ZC_KERNEL void k_ed_mul_base(const u64* k, u64* out, const u32* table, size_t n)
+{
+    __shared__ int8_t sdig[66 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    u64 l[5];
+    load5(l, k + 5 * (valid ? i : 0));
+    int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
+    if (!valid) top = -1;
+    top = wave_max_i32(top);
+    const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
+    if (valid) pt_store(out + 20 * i, Q);
+}
+// key generation: scalars -> compressed Ristretto public keys, (RISTRETTO_BASEPOINT * k).compress()
+ZC_KERNEL void k_ris_mul_base_compress(const u64* k, uint8_t* out, const u32* table, size_t n)
+{
+    __shared__ int8_t sdig[66 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    u64 l[5], w[4];
+    load5(l, k + 5 * (valid ? i : 0));
+    int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
+    if (!valid) top = -1;
+    top = wave_max_i32(top);
+    const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
+    fe_to_words256(w, ris_compress(Q));
+    if (valid) store_words256(out + 32 * i, w);
 }
 
 // ltr_bin_mul (MODE 1) / binary_naf_mul (MODE 2): limbs identical to the reference's variants

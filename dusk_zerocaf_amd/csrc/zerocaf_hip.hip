@@ -57,6 +57,8 @@ struct DevState {
     size_t msm_bytes = 0;
     void* fast = nullptr;               // fast scalar-mul window tables: 1 KB per lane
     size_t fast_bytes = 0;
+    void* base_table = nullptr;         // comb table of the basepoint: 66 x 8 cached points
+    size_t base_bytes = 0;
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -475,6 +477,7 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.bal) (void)hipFree(ds.bal);
         if (ds.msm) (void)hipFree(ds.msm);
         if (ds.fast) (void)hipFree(ds.fast);
+        if (ds.base_table) (void)hipFree(ds.base_table);
         if (ds.stream) (void)hipStreamDestroy(ds.stream);
     }
     delete ctx;
@@ -769,6 +772,43 @@ int zc_proj_to_extended(zc_ctx* ctx, const uint64_t* p, uint64_t* out, size_t n)
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
         hipLaunchKernelGGL(zc::k_proj_to_extended, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
+}
+
+// ---- fixed-base multiplication of the basepoint
+static int base_table(DevState& D, const zc::u32** table)
+{
+    if (!D.base_table) {
+        int rc = ensure(&D.base_table, &D.base_bytes, (size_t)zc::ZC_BASE_WINDOWS * 8 * 128);
+        if (rc) return rc;
+        hipLaunchKernelGGL(zc::k_base_table_build, dim3(1), dim3(64), 0, D.s(), (zc::u32*)D.base_table);
+        HIP_TRY(hipGetLastError());
+    }
+    *table = (const zc::u32*)D.base_table;
+    return ZC_OK;
+}
+int zc_ed_mul_base(zc_ctx* ctx, const uint64_t* k, uint64_t* out, size_t n)
+{
+    REQUIRE(k); REQUIRE(out);
+    Arg args[2] = {in_arg(k, 40), out_arg(out, 160)};
+    int inner = ZC_OK;
+    int rc = run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        const zc::u32* t = nullptr;
+        if ((inner = base_table(D, &t)) != ZC_OK) return;
+        hipLaunchKernelGGL(zc::k_ed_mul_base, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], t, cnt);
+    });
+    return rc ? rc : inner;
+}
+int zc_ris_mul_base_compress(zc_ctx* ctx, const uint64_t* k, uint8_t* out32, size_t n)
+{
+    REQUIRE(k); REQUIRE(out32);
+    Arg args[2] = {in_arg(k, 40), out_arg(out32, 32)};
+    int inner = ZC_OK;
+    int rc = run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        const zc::u32* t = nullptr;
+        if ((inner = base_table(D, &t)) != ZC_OK) return;
+        hipLaunchKernelGGL(zc::k_ris_mul_base_compress, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], t, cnt);
+    });
+    return rc ? rc : inner;
 }
 
 // ---- MSM: sum_i k_i * P_i (not in the reference).  Per GPU: bucket method (zc_msm.cuh) for

@@ -309,6 +309,19 @@ class Engine:
         self._call("zc_proj_to_extended", pp, po, n)
         return out
 
+    # ------------------------------------------------------------------ fixed-base (key generation)
+    def ed_mul_base(self, k):
+        k, pk, n = self._prep(k, 5, np.uint64)
+        out, po = self._alloc(k, n, 20, np.uint64)
+        self._call("zc_ed_mul_base", pk, po, n)
+        return out
+
+    def ris_mul_base_compress(self, k):
+        k, pk, n = self._prep(k, 5, np.uint64)
+        out, po = self._alloc(k, n, 32, np.uint8)
+        self._call("zc_ris_mul_base_compress", pk, po, n)
+        return out
+
     # ------------------------------------------------------------------ MSM (not in the reference)
     def msm(self, points, scalars):
         points, pp, n = self._prep(points, 20, np.uint64)

@@ -162,6 +162,14 @@ int zc_proj_add(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint64_t *out
 int zc_proj_double(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
 int zc_proj_to_extended(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
 
+/* Fixed-base multiplication of BASEPOINT (constants.rs:188-211) with a precomputed comb table:
+ * the correct counterpart of the reference's window_naf_mul (src/edwards.rs:155-171, which
+ * mis-indexes its table).  zc_ed_mul_base: k*B equal to `&BASEPOINT * &k` under == (not
+ * limb-identical).  zc_ris_mul_base_compress: (RISTRETTO_BASEPOINT * k).compress() -- key
+ * generation; the 32-byte outputs are bit-identical to the reference's.                     */
+int zc_ed_mul_base(zc_ctx *ctx, const uint64_t *k, uint64_t *out, size_t n);
+int zc_ris_mul_base_compress(zc_ctx *ctx, const uint64_t *k, uint8_t *out32, size_t n);
+
 /* ---- multi-scalar multiplication (not in the reference: sum_i k_i * P_i) -------- */
 /* out_point: one EdwardsPoint (HOST memory), equal to the reference's
  * sum of `&P_i * &k_i` as a group element (compare with ==, i.e. affine/compressed). */

@@ -473,6 +473,32 @@ def test_next_rows_elligator_validity_projective(eng, oracle, kats):
     assert eq(eng.proj_to_extended(A3), oracle.proj_to_extended(A3))
 
 
+def test_fixed_base_key_generation(eng, oracle):
+    """k * BASEPOINT from the comb table: same group element as the reference's `&BASEPOINT * &k`
+    (affine ==, identical Edwards / Ristretto encodings); the fused key-generation call returns
+    exactly (RISTRETTO_BASEPOINT * k).compress()."""
+    n = 6000
+    K = V.rand_scalars_np(n, V.SEED + 150, bits=249)
+    _edge_scalars(K)
+    base = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (n, 1))
+    want = oracle.ed_scalar_mul(base, K)
+    got = eng.ed_mul_base(K)
+    assert oracle.ed_eq(got, want).all()
+    assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
+    pk = eng.ris_mul_base_compress(K)
+    assert eq(pk, oracle.ris_compress(want))
+    big = 1 << 20
+    Kb = V.rand_scalars_np(big, V.SEED + 151, bits=249)
+    pkb = eng.ris_mul_base_compress(Kb)
+    idx = np.arange(0, big, 2053)
+    assert eq(pkb[idx], oracle.ris_compress(oracle.ed_scalar_mul(np.tile(base[:1], (len(idx), 1)), Kb[idx])))
+    # ECDH consistency on every element: k2 * (k1 * B) == k1 * (k2 * B) as encodings
+    K2 = V.rand_scalars_np(big, V.SEED + 152, bits=249)
+    s12, ok1 = eng.ris_roundtrip_mul(pkb, K2)
+    s21, ok2 = eng.ris_roundtrip_mul(eng.ris_mul_base_compress(K2), Kb)
+    assert ok1.all() and ok2.all() and eq(s12, s21)
+
+
 def test_msm_small(eng, oracle):
     for n in (1, 2, 3, 64, 257):                                  # scalar-mul + fold path
         P = V.base_multiples(oracle, n, V.SEED + 80 + n)
