@@ -215,13 +215,13 @@ def main():
         try:
             t = json.load(open(pmc))
             if args.workload == "scalar_mul":
-                roofline["traffic"] = round(t["scalar_mul"] * n / (1 << 20))
+                roofline["traffic"] = round(t["scalar_mul"] * n / (1 << 20)) if args.mode == "strict" else None
             elif args.workload == "fe_mul":
                 roofline["traffic"] = round(t["fe_mul_per_unit_bytes"] * n)
         except Exception:
             pass
     ub = os.path.join(ROOT, "profiles", "r01_ubench.json")
-    if args.workload != "fe_mul" and os.path.exists(ub):
+    if args.workload == "scalar_mul" and args.mode == "strict" and os.path.exists(ub):
         try:
             u = json.load(open(ub))
             mad_peak = float(u["v_mad_u64_u32_lane_ops_per_s"])
@@ -239,7 +239,7 @@ def main():
                 "valu_wave_insts_per_launch": insts, "mad_class_fraction": round(heavy, 3),
                 "v_mad_u64_u32_peak_lane_ops_per_s": mad_peak, "alu32_peak_lane_ops_per_s": alu_peak,
                 "issue_bound_ms": round(t_min * 1e3, 3),
-                "frac_of_issue_bound": round(t_min / kern_avg_s, 4) if args.workload == "scalar_mul" else None}
+                "frac_of_issue_bound": round(t_min / kern_avg_s, 4)}
         except Exception:
             pass
 
