@@ -480,8 +480,24 @@ ZC_DI int block_cost_rank(u32* __restrict__ skey, u32* __restrict__ sperm, u32 m
     return (int)sperm[tid];
 }
 
-// k_stride = 5 (one scalar per point) or 0 (one scalar for the whole batch:
-// mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191).
+// One scalar shared by the whole batch, passed by value in the kernel arguments
+// (mul_by_pow_2 / mul_by_cofactor, edwards.rs:174-191): no device copy of the scalar is needed.
+struct scalar_arg {
+    u64 l[5];
+};
+ZC_KERNEL void k_ed_scalar_mul_bcast(const u64* p, scalar_arg k, u64* out, size_t n)
+{
+    __shared__ u32 sk[9 * ZC_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    int nbits;
+    scalar_to_words(sk + tid, ZC_BLOCK, k.l, nbits);
+    const pt Q = scalar_mul_unified(pt_load(p + 20 * (valid ? i : 0)), sk + tid, ZC_BLOCK, valid ? nbits : 0);
+    if (valid) pt_store(out + 20 * i, Q);
+}
+
+// k_stride = 5 (one scalar per point).
 // idx != nullptr: batch-wide cost-sorted permutation (k_sm_cost_*); otherwise block-local ranking.
 ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
 {

@@ -249,15 +249,25 @@ const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt)
     return idx;
 }
 
-int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, bool broadcast_k, uint64_t* out, size_t n)
+int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
 {
     REQUIRE(p); REQUIRE(k); REQUIRE(out);
-    Arg args[3] = {in_arg(p, 160), Arg{k, 40, false, broadcast_k}, out_arg(out, 160)};
-    const size_t stride = broadcast_k ? 0 : 5;
+    Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        const zc::u32* idx = broadcast_k ? nullptr : balance_index(D, (const u64*)d[1], cnt);
+        const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
         hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
-                           (const u64*)d[1], stride, (u64*)d[2], idx, cnt);
+                           (const u64*)d[1], (size_t)5, (u64*)d[2], idx, cnt);
+    });
+}
+// the same scalar for every point, handed to the kernel by value
+int scalar_mul_bcast(zc_ctx* ctx, const uint64_t* p, const uint64_t (&k)[5], uint64_t* out, size_t n)
+{
+    REQUIRE(p); REQUIRE(out);
+    zc::scalar_arg ka;
+    for (int j = 0; j < 5; j++) ka.l[j] = k[j];
+    Arg args[2] = {in_arg(p, 160), out_arg(out, 160)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_scalar_mul_bcast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], ka, (u64*)d[1], cnt);
     });
 }
 
@@ -603,7 +613,7 @@ int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {
-    if (flags == ZC_SCALAR_MUL_STRICT) return scalar_mul_impl(ctx, p, k, false, out, n);
+    if (flags == ZC_SCALAR_MUL_STRICT) return scalar_mul_impl(ctx, p, k, out, n);
     if (flags == ZC_SCALAR_MUL_FAST) {
         REQUIRE(p); REQUIRE(k); REQUIRE(out);
         Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
@@ -625,27 +635,7 @@ int zc_ed_mul_by_pow_2(zc_ctx* ctx, const uint64_t* p, uint64_t kexp, uint64_t* 
     if (kexp >= 250) return fail(ZC_ERR_BAD_ARG, "Exponent can't be greater than the sub-group order");   // scalar.rs:531
     uint64_t k[5] = {0, 0, 0, 0, 0};
     k[kexp / 52] = 1ull << (kexp % 52);                  // Scalar::two_pow_k, scalar.rs:525-552
-    // the broadcast scalar is a host value: route it through a tiny device copy when p is on device
-    Residency r = RES_HOST;
-    int d = -1;
-    if (p) residency_of(p, &r, &d);
-    if (r == RES_DEVICE) {
-        if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
-        DevState* ds = nullptr;
-        for (auto& x : ctx->devs)
-            if (x.device == d) ds = &x;
-        if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
-        {
-            std::lock_guard<std::mutex> lock(ctx->mu);
-            HIP_TRY(hipSetDevice(ds->device));
-            int rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], 64);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(ds->tmp[1], k, 40, hipMemcpyHostToDevice, ds->s()));
-            HIP_TRY(hipStreamSynchronize(ds->s()));       // k[] is a stack buffer
-        }
-        return scalar_mul_impl(ctx, p, (const uint64_t*)ds->tmp[1], true, out, n);
-    }
-    return scalar_mul_impl(ctx, p, k, true, out, n);
+    return scalar_mul_bcast(ctx, p, k, out, n);
 }
 int zc_ed_mul_by_cofactor(zc_ctx* ctx, const uint64_t* p, uint64_t* out, size_t n)
 {
