@@ -47,6 +47,9 @@ struct DevState {
     hipStream_t stream = nullptr;       // owned
     hipStream_t borrowed = nullptr;     // set by zc_ctx_set_stream (device 0 only)
     bool use_borrowed = false;
+    hipStream_t copy_in = nullptr;      // host batches: upload / download streams of the chunk pipeline
+    hipStream_t copy_out = nullptr;
+    std::vector<hipEvent_t> ev;         // 2 per chunk: inputs landed, kernel done
     void* scratch[MAX_ARGS] = {};
     size_t scratch_bytes[MAX_ARGS] = {};
     void* tmp[2] = {};                  // zc_msm partials
@@ -76,7 +79,6 @@ struct Arg {
     const void* ptr;     // caller pointer (host or device), may be null when optional
     size_t elt_bytes;    // bytes per element
     bool is_out;
-    bool broadcast;      // a single element shared by the whole batch (not sliced)
 };
 
 enum Residency { RES_HOST = 0, RES_DEVICE = 1 };
@@ -114,9 +116,54 @@ int ensure(void** buf, size_t* have, size_t need)
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + zc::ZC_BLOCK - 1) / zc::ZC_BLOCK); }
 
+// Host batches of the long-running kernels (scalar multiplications: >= 10 ms per 2^20 elements)
+// move through the device in chunks so that only the first upload and the last download are
+// exposed. A chunk is a whole number of full-chip rounds of workgroups (2^17 lanes = 512 blocks),
+// otherwise every chunk pays a partially filled tail round: measured on 2^20 strict
+// scalar-muls, 4 x 2^18 takes 26.1 ms, 3 chunks 30.2 ms, 1 chunk 32.0 ms (kernel alone 22.5 ms).
+// Copy-bound calls (field / point element-wise ops) stay in one piece: pageable copies block the
+// calling thread, so chunking them buys no overlap. ZC_HOST_CHUNKS=k forces k chunks.
+constexpr size_t CHUNK_ROUND = (size_t)1 << 17;
+constexpr size_t MAX_CHUNKS = 4096;
+inline size_t host_chunk_elems(size_t cnt, bool heavy)
+{
+    const char* e = getenv("ZC_HOST_CHUNKS");
+    const long forced = e ? atol(e) : 0L;
+    size_t chunk = cnt;
+    if (forced > 0)
+        chunk = (cnt + forced - 1) / forced;
+    else if (heavy && cnt >= 4 * CHUNK_ROUND)
+        chunk = 2 * CHUNK_ROUND;
+    else if (heavy && cnt >= 2 * CHUNK_ROUND)
+        chunk = CHUNK_ROUND;
+    chunk = (chunk + 1023) / 1024 * 1024;
+    return std::max(chunk, (cnt + MAX_CHUNKS - 1) / MAX_CHUNKS);
+}
+// ZC_HOST_PIN=1 page-locks the caller's buffers for the duration of a call (hipHostRegister),
+// which makes the chunk copies truly asynchronous at the price of the registration itself.
+inline bool host_pin()
+{
+    const char* e = getenv("ZC_HOST_PIN");
+    return e && atoi(e) != 0;
+}
+struct HostPin {
+    std::vector<void*> held;
+    void add(void* p, size_t bytes)
+    {
+        if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess)
+            held.push_back(p);
+        else
+            (void)hipGetLastError();
+    }
+    ~HostPin()
+    {
+        for (void* p : held) (void)hipHostUnregister(p);
+    }
+};
+
 // Launch functor: receives device pointers in argument order, element count, device state.
 template <class Launch>
-int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch)
+int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bool heavy = false)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
     if (nargs > MAX_ARGS) return fail(ZC_ERR_BAD_ARG, "too many arguments");
@@ -153,45 +200,102 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch)
         return ZC_OK;
     }
 
-    // host buffers: shard into contiguous ranges, one per device (no exchange step)
+    // host buffers: shard into contiguous ranges, one per device (no exchange step); each range
+    // moves through the device in chunks so uploads, kernels and downloads overlap
     const size_t ndev = ctx->devs.size();
     const size_t per = (n + ndev - 1) / ndev;
+    HostPin pin;
+    if (host_pin())
+        for (int a = 0; a < nargs; a++)
+            if (args[a].ptr) pin.add(const_cast<void*>(args[a].ptr), args[a].elt_bytes * n);
+
+    struct Plan {
+        size_t lo = 0, cnt = 0, chunk = 0, nchunks = 0;
+        void* base[MAX_ARGS] = {};
+    };
+    std::vector<Plan> plans(ndev);
+    size_t max_chunks = 0;
     for (size_t di = 0; di < ndev; di++) {
-        const size_t lo = di * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        const size_t cnt = hi - lo;
+        Plan& pl = plans[di];
+        pl.lo = di * per;
+        const size_t hi = std::min(n, pl.lo + per);
+        if (pl.lo >= hi) break;
+        pl.cnt = hi - pl.lo;
+        pl.chunk = host_chunk_elems(pl.cnt, heavy);
+        pl.nchunks = (pl.cnt + pl.chunk - 1) / pl.chunk;
+        max_chunks = std::max(max_chunks, pl.nchunks);
         DevState& ds = ctx->devs[di];
         HIP_TRY(hipSetDevice(ds.device));
+        for (int a = 0; a < nargs; a++) {
+            if (!args[a].ptr) continue;
+            int rc = ensure(&ds.scratch[a], &ds.scratch_bytes[a], args[a].elt_bytes * pl.cnt);
+            if (rc) return rc;
+            pl.base[a] = ds.scratch[a];
+        }
+        while (ds.ev.size() < 2 * pl.nchunks) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ds.ev.push_back(e);
+        }
+    }
+    // chunk j of device di: upload on copy_in, kernel on the context stream, download on copy_out
+    auto upload_and_launch = [&](size_t di, size_t j) -> int {
+        Plan& pl = plans[di];
+        if (j >= pl.nchunks) return ZC_OK;
+        DevState& ds = ctx->devs[di];
+        HIP_TRY(hipSetDevice(ds.device));
+        const size_t off = j * pl.chunk, cnt = std::min(pl.chunk, pl.cnt - off);
         void* dptr[MAX_ARGS];
         for (int a = 0; a < nargs; a++) {
-            dptr[a] = nullptr;
-            if (!args[a].ptr) continue;
-            const size_t bytes = args[a].broadcast ? args[a].elt_bytes : args[a].elt_bytes * cnt;
-            int rc = ensure(&ds.scratch[a], &ds.scratch_bytes[a], bytes);
-            if (rc) return rc;
-            dptr[a] = ds.scratch[a];
-            if (!args[a].is_out) {
-                const char* src = (const char*)args[a].ptr + (args[a].broadcast ? 0 : args[a].elt_bytes * lo);
-                HIP_TRY(hipMemcpyAsync(dptr[a], src, bytes, hipMemcpyHostToDevice, ds.s()));
-            }
+            dptr[a] = pl.base[a] ? (char*)pl.base[a] + args[a].elt_bytes * off : nullptr;
+            if (!args[a].ptr || args[a].is_out) continue;
+            const char* src = (const char*)args[a].ptr + args[a].elt_bytes * (pl.lo + off);
+            HIP_TRY(hipMemcpyAsync(dptr[a], src, args[a].elt_bytes * cnt, hipMemcpyHostToDevice, ds.copy_in));
         }
+        HIP_TRY(hipEventRecord(ds.ev[2 * j], ds.copy_in));
+        HIP_TRY(hipStreamWaitEvent(ds.s(), ds.ev[2 * j], 0));
         launch(dptr, cnt, ds);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ds.ev[2 * j + 1], ds.s()));
+        return ZC_OK;
+    };
+    auto download = [&](size_t di, size_t j) -> int {
+        Plan& pl = plans[di];
+        if (j >= pl.nchunks) return ZC_OK;
+        DevState& ds = ctx->devs[di];
+        HIP_TRY(hipSetDevice(ds.device));
+        const size_t off = j * pl.chunk, cnt = std::min(pl.chunk, pl.cnt - off);
+        HIP_TRY(hipStreamWaitEvent(ds.copy_out, ds.ev[2 * j + 1], 0));
         for (int a = 0; a < nargs; a++) {
             if (!args[a].ptr || !args[a].is_out) continue;
-            char* dst = (char*)const_cast<void*>(args[a].ptr) + args[a].elt_bytes * lo;
-            HIP_TRY(hipMemcpyAsync(dst, dptr[a], args[a].elt_bytes * cnt, hipMemcpyDeviceToHost, ds.s()));
+            char* dst = (char*)const_cast<void*>(args[a].ptr) + args[a].elt_bytes * (pl.lo + off);
+            HIP_TRY(hipMemcpyAsync(dst, (char*)pl.base[a] + args[a].elt_bytes * off, args[a].elt_bytes * cnt, hipMemcpyDeviceToHost, ds.copy_out));
         }
+        return ZC_OK;
+    };
+    // Copies from/to pageable memory block the calling thread, so the issue order keeps
+    // LOOKAHEAD kernels queued on every device before the thread waits on a download.
+    constexpr size_t LOOKAHEAD = 2;
+    int rc = ZC_OK;
+    for (size_t j = 0; j < std::min(LOOKAHEAD, max_chunks) && !rc; j++)
+        for (size_t di = 0; di < ndev && !rc; di++) rc = upload_and_launch(di, j);
+    for (size_t j = 0; j < max_chunks && !rc; j++) {
+        for (size_t di = 0; di < ndev && !rc; di++) rc = download(di, j);
+        for (size_t di = 0; di < ndev && !rc; di++) rc = upload_and_launch(di, j + LOOKAHEAD);
     }
     for (size_t di = 0; di < ndev; di++) {
-        HIP_TRY(hipSetDevice(ctx->devs[di].device));
-        HIP_TRY(hipStreamSynchronize(ctx->devs[di].s()));
+        if (!plans[di].cnt) continue;
+        DevState& ds = ctx->devs[di];
+        HIP_TRY(hipSetDevice(ds.device));
+        HIP_TRY(hipStreamSynchronize(ds.copy_in));
+        HIP_TRY(hipStreamSynchronize(ds.s()));
+        HIP_TRY(hipStreamSynchronize(ds.copy_out));
     }
-    return ZC_OK;
+    return rc;
 }
 
-inline Arg in_arg(const void* p, size_t b) { return Arg{p, b, false, false}; }
-inline Arg out_arg(void* p, size_t b) { return Arg{p, b, true, false}; }
+inline Arg in_arg(const void* p, size_t b) { return Arg{p, b, false}; }
+inline Arg out_arg(void* p, size_t b) { return Arg{p, b, true}; }
 
 #define REQUIRE(p) \
     if (!(p)) return fail(ZC_ERR_BAD_ARG, "null pointer: " #p)
@@ -214,7 +318,7 @@ int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint6
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
         const bool stream = k_stream && cnt * elt * 3 > STREAM_BYTES && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
         hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
-    });
+    }, elt == 0);
 }
 int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
 {
@@ -257,7 +361,7 @@ int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t*
         const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
         hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
                            (const u64*)d[1], (size_t)5, (u64*)d[2], idx, cnt);
-    });
+    }, true);
 }
 // the same scalar for every point, handed to the kernel by value
 int scalar_mul_bcast(zc_ctx* ctx, const uint64_t* p, const uint64_t (&k)[5], uint64_t* out, size_t n)
@@ -268,7 +372,7 @@ int scalar_mul_bcast(zc_ctx* ctx, const uint64_t* p, const uint64_t (&k)[5], uin
     Arg args[2] = {in_arg(p, 160), out_arg(out, 160)};
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
         hipLaunchKernelGGL(zc::k_ed_scalar_mul_bcast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], ka, (u64*)d[1], cnt);
-    });
+    }, true);
 }
 
 // ---------------------------------------------------------------- MSM device pipeline
@@ -463,6 +567,8 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         ds.device = id;
         hipError_t e = hipSetDevice(id);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_out, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete ctx;
             return fail(ZC_ERR_HIP, "stream creation", e);
@@ -488,6 +594,9 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.msm) (void)hipFree(ds.msm);
         if (ds.fast) (void)hipFree(ds.fast);
         if (ds.base_table) (void)hipFree(ds.base_table);
+        for (hipEvent_t e : ds.ev) (void)hipEventDestroy(e);
+        if (ds.copy_in) (void)hipStreamDestroy(ds.copy_in);
+        if (ds.copy_out) (void)hipStreamDestroy(ds.copy_out);
         if (ds.stream) (void)hipStreamDestroy(ds.stream);
     }
     delete ctx;
@@ -623,7 +732,7 @@ int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t
             if ((inner = ensure(&D.fast, &D.fast_bytes, lanes * 1024)) != ZC_OK) return;
             hipLaunchKernelGGL(zc::k_ed_scalar_mul_fast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
                                (const u64*)d[1], (size_t)5, (u64*)d[2], (zc::u32*)D.fast, cnt);
-        });
+        }, true);
         return rc ? rc : inner;
     }
     if (flags == ZC_SCALAR_MUL_LTR_BIN) return binop(ctx, zc::k_ed_scalar_mul_ltr_bin, nullptr, p, k, out, n, 0);
@@ -716,7 +825,7 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
         const size_t lanes = (size_t)grid_for(cnt) * zc::ZC_BLOCK;
         if ((inner = ensure(&D.fast, &D.fast_bytes, lanes * 1024)) != ZC_OK) return;
         hipLaunchKernelGGL(zc::k_ris_roundtrip_mul_fast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], (zc::u32*)D.fast, cnt);
-    });
+    }, true);
     return rc ? rc : inner;
 }
 

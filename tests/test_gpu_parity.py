@@ -607,3 +607,41 @@ def test_device_resident_buffers(eng, oracle):
             eng.fe_mul(da, b)                                     # host/device mix is refused
     finally:
         eng.use_own_stream()
+
+
+def test_host_batches_move_in_chunks(eng, oracle, monkeypatch):
+    """Host (numpy) batches of the scalar-mul family pass through the device in chunks that
+    overlap copies with kernels; any chunking must give the bytes of the one-piece run, with
+    ragged last chunks, optional masks and two device slots."""
+    import dusk_zerocaf_amd as z
+    n = (1 << 18) + 777                                            # default policy: 2^17 + 2^17 + 777
+    base = V.base_multiples(oracle, 2048, V.SEED + 130)
+    P = np.tile(base, (n // 2048 + 1, 1))[:n].copy()
+    K = V.rand_scalars_np(n, V.SEED + 131, bits=252)
+    enc = eng.ris_compress(P)
+    enc[5::1001, 31] |= 0x80                                       # some undecodable encodings
+    monkeypatch.setenv("ZC_HOST_CHUNKS", "1")
+    q1 = eng.ed_scalar_mul(P, K)
+    r1, ok1 = eng.ris_roundtrip_mul(enc, K)
+    c1 = eng.ed_mul_by_cofactor(P)
+    f1 = eng.fe_mul(K, K)
+    sub = np.r_[0:256, (1 << 17) - 128:(1 << 17) + 128, n - 300:n]   # across chunk seams and the tail
+    assert eq(q1[sub], oracle.ed_scalar_mul(P[sub], K[sub]))
+    for chunks in (None, "3", "7"):
+        if chunks is None:
+            monkeypatch.delenv("ZC_HOST_CHUNKS")
+        else:
+            monkeypatch.setenv("ZC_HOST_CHUNKS", chunks)
+        assert eq(eng.ed_scalar_mul(P, K), q1)
+        fast = eng.ed_scalar_mul(P, K, flags=z.FAST)             # same group element: compare encodings
+        assert eq(eng.ed_compress(fast[sub])[0], eng.ed_compress(q1[sub])[0])
+        r, ok = eng.ris_roundtrip_mul(enc, K)
+        assert eq(r, r1) and eq(ok, ok1) and not ok[5] and ok[6]
+        assert eq(eng.ed_mul_by_cofactor(P), c1)
+        assert eq(eng.fe_mul(K, K), f1)
+    monkeypatch.setenv("ZC_HOST_CHUNKS", "5")
+    two = z.Engine([0, 0])
+    try:
+        assert eq(two.ed_scalar_mul(P, K), q1)
+    finally:
+        two.close()
