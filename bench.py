@@ -293,9 +293,14 @@ def main():
                                 "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
                                 "ristretto": "Ristretto decompress->scalar-mul->compress (BASELINE configs[3] shape)",
                                 "msm": "Pippenger MSM, 249-bit scalars, one shard per GPU (BASELINE configs[4] shape)"}[args.workload],
-                   "units_per_gpu_per_step": n, "sharding": "contiguous ranges, no collective",
-                   "mode": "strict (reference formula sequence, identical X:Y:Z:T limbs)" if args.mode == "strict" or args.workload != "scalar_mul"
-                           else "FAST (non-strict extra: same group element / encodings, limbs differ by a projective factor)"},
+                   "units_per_gpu_per_step": n,
+                   "sharding": "contiguous ranges; all-gather of one 160-byte partial per rank + ordered fold" if args.workload == "msm"
+                               else "contiguous ranges, no collective",
+                   "mode": {"scalar_mul": "strict (reference formula sequence, identical X:Y:Z:T limbs)" if args.mode == "strict"
+                                          else "FAST (non-strict extra: same group element / encodings, limbs differ by a projective factor)",
+                            "fe_mul": "bit-exact canonical limbs",
+                            "ristretto": "bit-exact 32-byte encodings and ok mask",
+                            "msm": "result compared as a group element (canonical encoding)"}[args.workload]},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_spot_check": checked,

@@ -12,7 +12,8 @@
 //   5. k_msm_segments : running-sum reduction of each window in segments of SEG buckets
 //                       (sum_seg = sum (d - lo + 1) B_d, acc_seg = sum B_d)
 //   6. existing kernels: (lo - 1) * acc_seg via k_ed_scalar_mul, k_ed_add, k_ed_fold_pairs down
-//      to one point per window, 2^(c w) * S_w via k_ed_scalar_mul, final fold.
+//      to one point per window
+//   7. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling
 #pragma once
 #include "zc_kernels.cuh"
 
@@ -31,7 +32,7 @@ ZC_DI u32 scalar_digit(const u64 (&l)[5], int w, int c)
     return (u32)x & ((1u << c) - 1);
 }
 
-// largest scalar bit length of the shard (wave reduce, one atomicMax per wave): windows above it
+// largest scalar bit length of the shard (wave reduce, at most one atomicMax per wave): windows above it
 // hold only zero digits and are not generated at all
 ZC_KERNEL void k_msm_maxbits(const u64* k, int* maxbits, size_t n)
 {
@@ -47,7 +48,8 @@ ZC_KERNEL void k_msm_maxbits(const u64* k, int* maxbits, size_t n)
         }
     }
     bits = wave_max_i32(bits);
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(maxbits, bits);
+    // almost every wave sees the batch maximum: look before the (serialised) atomic
+    if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, bits);
 }
 
 ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c, int W)
@@ -143,6 +145,53 @@ ZC_KERNEL void k_msm_segments(const u64* buckets, u64* seg_sum, u64* seg_acc, u6
     u64* k = seg_scalar + 5 * s;
     k[0] = (lo == 0) ? 0 : lo - 1;
     k[1] = 0; k[2] = 0; k[3] = 0; k[4] = 0;
+}
+
+// ---------------------------------------------------------------- window combination
+// S = sum_w 2^(c w) S_w by Horner's rule: c doublings and one addition per window, about 250
+// dependent doublings on ONE point, so the step is pure latency.  A quad of lanes shares each
+// doubling: phase 1 squares X, Y, Z, X+Y on lanes 0..3, phase 2 forms E*F, G*H, F*G, E*H
+// (dbl-2008-hwcd, a = -1), and DPP quad broadcasts hand the four results round; a doubling then
+// costs one squaring plus one multiplication of latency instead of eight.  Result compared as a
+// group element (zc_msm contract), so the dedicated doubling is admissible here.
+template <int J>
+ZC_DI fe quad_bcast(const fe& x)
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.v[i], J * 0x55, 0xF, 0xF, false);
+    return r;
+}
+ZC_DI fe fe_by_role(int role, const fe& a, const fe& b, const fe& c, const fe& d)
+{
+    return fe_select(role < 2, fe_select(role == 0, a, b), fe_select(role == 2, c, d));
+}
+ZC_DI pt pt_double_quad(const pt& p, int role)
+{
+    const fe sq = fp_sqr(fe_by_role(role, p.X, p.Y, p.Z, fe_add(p.X, p.Y)));
+    const fe A = quad_bcast<0>(sq), B = quad_bcast<1>(sq), ZZ = quad_bcast<2>(sq), S = quad_bcast<3>(sq);
+    const fe E = fp_sub(fp_sub(S, A), B);
+    const fe G = fp_sub(B, A);
+    const fe F = fp_sub(fp_sub(G, ZZ), ZZ);
+    const fe H = fp_sub(fp_neg(A), B);
+    const fe m = fp_mul(fe_by_role(role, E, G, F, E), fe_by_role(role, F, H, G, H));
+    pt r;
+    r.X = quad_bcast<0>(m);
+    r.Y = quad_bcast<1>(m);
+    r.Z = quad_bcast<2>(m);
+    r.T = quad_bcast<3>(m);
+    return r;
+}
+// one wave; windows[w] = S_w (W points); out = sum_w 2^(c w) S_w
+ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c)
+{
+    const int role = threadIdx.x & 3;
+    pt Q = pt_load(windows + 20 * (size_t)(W - 1));
+    for (int w = W - 2; w >= 0; w--) {
+        for (int i = 0; i < c; i++) Q = pt_double_quad(Q, role);
+        Q = pt_add(Q, pt_load(windows + 20 * (size_t)w));
+    }
+    if (threadIdx.x == 0) pt_store(out, Q);
 }
 
 }  // namespace zc

@@ -139,28 +139,6 @@ inline size_t host_chunk_elems(size_t cnt, bool heavy)
     chunk = (chunk + 1023) / 1024 * 1024;
     return std::max(chunk, (cnt + MAX_CHUNKS - 1) / MAX_CHUNKS);
 }
-// ZC_HOST_PIN=1 page-locks the caller's buffers for the duration of a call (hipHostRegister),
-// which makes the chunk copies truly asynchronous at the price of the registration itself.
-inline bool host_pin()
-{
-    const char* e = getenv("ZC_HOST_PIN");
-    return e && atoi(e) != 0;
-}
-struct HostPin {
-    std::vector<void*> held;
-    void add(void* p, size_t bytes)
-    {
-        if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess)
-            held.push_back(p);
-        else
-            (void)hipGetLastError();
-    }
-    ~HostPin()
-    {
-        for (void* p : held) (void)hipHostUnregister(p);
-    }
-};
-
 // Launch functor: receives device pointers in argument order, element count, device state.
 template <class Launch>
 int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bool heavy = false)
@@ -204,10 +182,6 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bo
     // moves through the device in chunks so uploads, kernels and downloads overlap
     const size_t ndev = ctx->devs.size();
     const size_t per = (n + ndev - 1) / ndev;
-    HostPin pin;
-    if (host_pin())
-        for (int a = 0; a < nargs; a++)
-            if (args[a].ptr) pin.add(const_cast<void*>(args[a].ptr), args[a].elt_bytes * n);
 
     struct Plan {
         size_t lo = 0, cnt = 0, chunk = 0, nchunks = 0;
@@ -476,7 +450,6 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         u64* seg_acc = cv.take<u64>(nseg * 20);
         u64* seg_k = cv.take<u64>(nseg * 5);
         u64* fold_b = cv.take<u64>((nseg / 2 + 1) * 20);
-        u64* win_k = cv.take<u64>((size_t)W * 5);
         if (!pass) {
             int rc = ensure(&D.msm, &D.msm_bytes, cv.off);
             if (rc) return rc;
@@ -510,17 +483,9 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             left /= 2;
             std::swap(cur, nxt);
         }
-        // S_w <- 2^(c w) * S_w, then fold the W window results
-        std::vector<uint64_t> wk((size_t)W * 5, 0);
-        for (int w = 0; w < W; w++) {
-            const int bit = c * w;
-            wk[(size_t)w * 5 + bit / 52] = 1ull << (bit % 52);
-        }
-        HIP_TRY(hipMemcpyAsync(win_k, wk.data(), wk.size() * 8, hipMemcpyHostToDevice, D.s()));
-        HIP_TRY(hipStreamSynchronize(D.s()));              // wk is a local buffer
-        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(W)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, (const u64*)win_k, (size_t)5, cur,
-                           (const zc::u32*)nullptr, (size_t)W);
-        *result = fold_all(D, cur, nxt, (size_t)W);
+        // sum_w 2^(c w) S_w
+        hipLaunchKernelGGL(zc::k_msm_window_combine, dim3(1), dim3(64), 0, D.s(), (const u64*)cur, nxt, W, c);
+        *result = nxt;
         HIP_TRY(hipGetLastError());
     }
     return ZC_OK;

@@ -645,3 +645,35 @@ def test_host_batches_move_in_chunks(eng, oracle, monkeypatch):
         assert eq(two.ed_scalar_mul(P, K), q1)
     finally:
         two.close()
+
+
+def test_concurrent_callers_share_a_context(eng, oracle):
+    """The reference's functions are pure and re-entrant; the ABI promises the same
+    for calls on one context from several threads (ctypes drops the GIL during a call)."""
+    import threading
+    n = 6000
+    P = V.base_multiples(oracle, n, V.SEED + 140)
+    K = V.rand_scalars_np(n, V.SEED + 141, bits=252)
+    a, b = V.rand_fe_np(n, V.SEED + 142), V.rand_fe_np(n, V.SEED + 143)
+    want = {"sm": oracle.ed_scalar_mul(P, K), "mul": oracle.fe_mul(a, b), "pow2": oracle.ed_mul_by_pow_2(P, 7),
+            "msm": oracle.ed_compress(oracle.msm_naive(P[:4500], K[:4500]))[0]}
+    got, errs = {}, []
+
+    def run(name, f, reps):
+        try:
+            for _ in range(reps):
+                got[name] = f()
+        except Exception as e:                                     # noqa: BLE001
+            errs.append((name, e))
+
+    ts = [threading.Thread(target=run, args=("sm", lambda: eng.ed_scalar_mul(P, K), 3)),
+          threading.Thread(target=run, args=("mul", lambda: eng.fe_mul(a, b), 40)),
+          threading.Thread(target=run, args=("pow2", lambda: eng.ed_mul_by_pow_2(P, 7), 6)),
+          threading.Thread(target=run, args=("msm", lambda: eng.ed_compress(eng.msm(P[:4500], K[:4500]))[0], 6))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for name in want:
+        assert eq(got[name], want[name]), name

@@ -1,7 +1,7 @@
 """Time the host-pointer (PCIe-inclusive) path of zc_ed_scalar_mul against the chunk count.
 
 Usage: python tools/host_path.py [log2_n]
-One JSON line per (chunks, pin) setting: best-of-7 wall time of the C-ABI call with numpy (pageable)
+One JSON line per chunk count: best-of-7 wall time of the C-ABI call with numpy (pageable)
 buffers, output buffer reused ("warm") and freshly allocated ("fresh"), device-resident time beside it.
 """
 import json
@@ -51,18 +51,16 @@ def main():
         o = np.empty_like(P)
         eng._call("zc_ed_scalar_mul", P.ctypes.data, k.ctypes.data, o.ctypes.data, n, 0)
 
-    for pin in ("0", "1"):
-        for chunks in ("auto", "1", "2", "3", "4", "6", "8", "12", "16", "24", "32"):
-            os.environ["ZC_HOST_PIN"] = pin
-            if chunks == "auto":
-                os.environ.pop("ZC_HOST_CHUNKS", None)
-            else:
-                os.environ["ZC_HOST_CHUNKS"] = chunks
-            tw, tf = best(warm), best(fresh)
-            assert np.array_equal(out, ref)
-            print(json.dumps({"op": "ed_scalar_mul", "n": n, "chunks": chunks, "pin": pin, "warm_ms": round(tw * 1e3, 2),
-                              "fresh_ms": round(tf * 1e3, 2), "device_ms": round(t_dev * 1e3, 2),
-                              "warm_units_per_s": round(n / tw)}))
+    for chunks in ("auto", "1", "2", "3", "4", "6", "8", "12", "16", "24", "32"):
+        if chunks == "auto":
+            os.environ.pop("ZC_HOST_CHUNKS", None)
+        else:
+            os.environ["ZC_HOST_CHUNKS"] = chunks
+        tw, tf = best(warm), best(fresh)
+        assert np.array_equal(out, ref)
+        print(json.dumps({"op": "ed_scalar_mul", "n": n, "chunks": chunks, "warm_ms": round(tw * 1e3, 2),
+                          "fresh_ms": round(tf * 1e3, 2), "device_ms": round(t_dev * 1e3, 2),
+                          "warm_units_per_s": round(n / tw)}))
 
 
 if __name__ == "__main__":
