@@ -633,6 +633,47 @@ ZC_DI bool ed_to_affine(fe& x, fe& y, const pt& p)
     y = fp_mul(p.Y, zi);
     return !fp_is_zero(p.Z);
 }
+// One lane's share of a batched affine conversion: Montgomery's trick over the Z coordinates of
+// `c` consecutive points (as fe_invert_chunk: plain limbs are used as Montgomery residues, prefix
+// products wait in the first 36 bytes of each 80-byte output record), then x = X/Z, y = Y/Z.
+// Z = 0 (the reference's inverse panics) takes the neutral value and yields (0, 0) / ok = 0.
+ZC_DI void ed_to_affine_chunk(const u64* p, u64* xy, uint8_t* ok, size_t n, size_t lo, int c)
+{
+    const int cnt = (int)((n - lo < (size_t)c) ? (n - lo) : (size_t)c);
+    const fe neutral = fe_one_m<FP>();
+    fe acc = neutral;
+    for (int j = 0; j < cnt; j++) {
+        u64 l[5];
+        load5(l, p + 20 * (lo + j) + 10);
+        const fe z = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
+        u32* slot = reinterpret_cast<u32*>(xy + 10 * (lo + j));
+#pragma unroll
+        for (int w = 0; w < 9; w++) slot[w] = acc.v[w];
+        acc = fp_mul(acc, z);
+    }
+    fe inv = mont_from<FP>(mont_from<FP>(fp_invert(acc)));
+    for (int j = cnt - 1; j >= 0; j--) {
+        u64 lx[5], ly[5], lz[5], r[5];
+        load5(lx, p + 20 * (lo + j));
+        load5(ly, p + 20 * (lo + j) + 5);
+        load5(lz, p + 20 * (lo + j) + 10);
+        const bool zero = limbs52_all_zero(lz);
+        const fe z = fe_select(zero, neutral, fe_from_limbs52(lz));
+        const u32* slot = reinterpret_cast<const u32*>(xy + 10 * (lo + j));
+        fe pre;
+#pragma unroll
+        for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
+        const fe zinv = mont_to<FP>(fp_mul(inv, pre));      // (1/Z) R
+        inv = fp_mul(inv, z);
+        fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(fp_mul(fe_from_limbs52(lx), zinv))));
+        if (zero) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
+        store5(xy + 10 * (lo + j), r);
+        fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(fp_mul(fe_from_limbs52(ly), zinv))));
+        if (zero) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
+        store5(xy + 10 * (lo + j) + 5, r);
+        if (ok) ok[lo + j] = zero ? 0 : 1;
+    }
+}
 // Edwards equality = affine equality (edwards.rs:360-364, 1044-1048), cross-multiplied
 ZC_DI bool ed_eq(const pt& a, const pt& b)
 {
@@ -641,22 +682,37 @@ ZC_DI bool ed_eq(const pt& a, const pt& b)
     return ex && ey && !fp_is_zero(a.Z) && !fp_is_zero(b.Z);
 }
 // Edwards compress (edwards.rs:613-629 + find_xx :200-204): y | sign << 255 where
-// sign = (mod_sqrt(xx, 0) != x).  One inversion shared by Z and the find_xx denominator.
+// sign = (mod_sqrt(xx, 0) != x), xx = (y^2 - 1)/(d y^2 + 1) = u/v with u = Y^2 - Z^2,
+// v = d Y^2 + Z^2.  ONE exponentiation serves the square root and the inversion of Z:
+//   E  = (u v^7 Z^8)^((p-5)/8) = a^((q-1)/2) (v Z)^-4          (a = u/v, q = (p-1)/4)
+//   x0 = u v^3 Z^4 E = a^((q+1)/2)       -- the value mod_sqrt starts from (field.rs:410)
+//   t  = a^q = v x0^2 / u in {1, -1}     -- -1: root is x0 * 6^q (Tonelli-Shanks correction)
+//   E x0 = t (v Z)^-4   =>   1/Z = t E x0 v^4 Z^3
+// and mod_sqrt(xx) == X/Z is tested as r Z == X.  u == 0 (x = 0: the identity and (0,-1)) has
+// a^q = 0, there y = +-1 is read off Y == +-Z.  Same bytes and ok mask as the reference's
+// affine conversion + find_xx + Tonelli-Shanks; failures (Z = 0, v = 0, non-residue) -> false.
 ZC_DI bool ed_compress(u64 (&w)[4], const pt& p)
 {
     const fe Y2 = fp_sqr(p.Y), Z2 = fp_sqr(p.Z);
-    const fe den = fe_add(fp_mul(fe_const<FP>(ModP::D_M), Y2), Z2);   // d*Y^2 + Z^2 (lazy)
-    const fe winv = fp_invert(fp_mul(p.Z, den));
-    const fe zinv = fp_mul(winv, den);
-    const fe x = fp_mul(p.X, zinv), y = fp_mul(p.Y, zinv);
-    const fe xx = fp_mul(fp_mul(fp_sub(Y2, Z2), winv), p.Z);   // (y^2 - 1)/(d*y^2 + 1)
-    fe r;
-    const bool have = fp_ts_sqrt(r, xx);
-    const bool ok = have && !fp_is_zero(p.Z) && !fp_is_zero(den);
-    const bool sign = !fp_eq(r, x);
+    const fe u = fe_reduce<FP>(fp_sub(Y2, Z2));
+    const fe v = fe_reduce<FP>(fe_add(fp_mul(fe_const<FP>(ModP::D_M), Y2), Z2));
+    const fe Z4 = fp_sqr(Z2);
+    const fe v2 = fp_sqr(v), v3 = fp_mul(v2, v), v4 = fp_sqr(v2);
+    const fe E = fp_pow(fp_mul(fp_mul(u, fp_mul(v4, v3)), fp_sqr(Z4)), ZC_EXP_P58, ModP::EXP_P58_BITS);
+    const fe x0 = fp_mul(fp_mul(fp_mul(u, v3), Z4), E);
+    const fe check = fp_mul(v, fp_sqr(x0));
+    const bool t_is_one = fe_eq_canon(fp_canon(check), fp_canon(u));
+    const bool t_is_m1 = fe_is_zero_canon(fp_canon(fe_add(check, u)));
+    const fe r = fe_select(t_is_one, x0, fp_mul(x0, fe_const<FP>(ModP::SIX_POW_Q_M)));
+    fe zinv = fp_mul(fp_mul(fp_mul(E, x0), v4), fp_mul(Z2, p.Z));
+    zinv = fe_select(t_is_one, zinv, fe_reduce<FP>(fp_neg(zinv)));
+    fe y = fp_mul(p.Y, zinv);
+    const bool u_zero = fp_is_zero(u);
+    y = fe_select(u_zero, fe_select(fp_eq(p.Y, p.Z), fe_one_m<FP>(), fe_const<FP>(ModP::MINUS_ONE_M)), y);
+    const bool sign = !fp_eq(fp_mul(r, p.Z), p.X);
     fe_to_words256(w, fp_canon(y));
     w[3] |= (u64)(sign ? 1 : 0) << 63;
-    return ok;
+    return (t_is_one || t_is_m1) && !fp_is_zero(p.Z) && !fp_is_zero(v);
 }
 // Tonelli-Shanks value of u/v with ONE exponentiation and no inversion: for p = 5 (mod 8),
 // (u v^3)(u v^7)^((p-5)/8) = (u/v)^((p+3)/8) = a^((q+1)/2) with a = u/v, q = (p-1)/4 -- exactly

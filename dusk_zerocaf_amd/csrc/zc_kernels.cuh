@@ -683,6 +683,12 @@ ZC_KERNEL void k_ed_to_affine(const u64* p, u64* xy, uint8_t* ok, size_t n)
     fe_store_canon<FP>(xy + 10 * i + 5, y);
     if (ok) ok[i] = o ? 1 : 0;
 }
+// large batches: one inversion per `c` consecutive points (ed_to_affine_chunk)
+ZC_KERNEL void k_ed_to_affine_chunked(const u64* p, u64* xy, uint8_t* ok, size_t n, int c)
+{
+    const size_t lo = gid() * (size_t)c;
+    if (lo < n) ed_to_affine_chunk(p, xy, ok, n, lo, c);
+}
 ZC_KERNEL void k_ed_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 {
     const size_t i = gid();

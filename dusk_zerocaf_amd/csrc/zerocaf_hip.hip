@@ -720,7 +720,14 @@ int zc_ed_to_affine(zc_ctx* ctx, const uint64_t* p, uint64_t* xy, uint8_t* ok, s
     REQUIRE(p); REQUIRE(xy);
     Arg args[3] = {in_arg(p, 160), out_arg(xy, 80), out_arg(ok, 1)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+        size_t c = cnt / 131072;                           // as zc_fe_invert: >= 2 waves per SIMD stay busy
+        if (c > 64) c = 64;
+        if (c < 2) {
+            hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+        } else {
+            const size_t lanes = (cnt + c - 1) / c;
+            hipLaunchKernelGGL(zc::k_ed_to_affine_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt, (int)c);
+        }
     });
 }
 int zc_ed_eq(zc_ctx* ctx, const uint64_t* p, const uint64_t* q, uint8_t* eq, size_t n)

@@ -134,6 +134,28 @@ def test_emul_codecs(emul, oracle):
     emul.emul_ed_compress(p(P), p(enc), p(ok), C.c_size_t(n))
     wenc, wok = oracle.ed_compress(P)
     assert np.array_equal(ok, wok) and np.array_equal(enc.view(np.uint8).reshape(n, 32), wenc)
+    # edge rows: x = 0 points with a non-trivial Z, scaled representatives, junk (off-curve,
+    # Z = 0, non-residue xx): same ok mask everywhere, same bytes wherever the reference succeeds
+    E = V.base_multiples(oracle, 64, V.SEED + 10)
+    lam = V.limbs_array(V.rand_fe(64, V.SEED + 11))
+    for c in range(4):
+        E[:, 5 * c:5 * c + 5] = oracle.fe_mul(E[:, 5 * c:5 * c + 5], lam)      # (lX : lY : lZ : lT)
+    z = lam[40]                                                   # past rand_fe's edge values (0, 1, ...)
+    E[0] = np.concatenate([np.zeros(5, dtype=np.uint64), z, z, np.zeros(5, dtype=np.uint64)])             # (0, 1)
+    E[1] = np.concatenate([np.zeros(5, dtype=np.uint64), oracle.fe_neg(z[None])[0], z, np.zeros(5, dtype=np.uint64)])   # (0, -1)
+    E[2, 10:15] = 0                                               # Z = 0
+    E[3:24] = np.concatenate([V.limbs_array(V.rand_fe(21, V.SEED + 12 + c)) for c in range(4)], axis=1)   # junk
+    wxy, wok = oracle.ed_to_affine(E)                             # one inversion per chunk of points
+    for c in (2, 5, 64):
+        xy, aok = np.empty((64, 10), dtype=np.uint64), np.empty(64, dtype=np.uint8)
+        emul.emul_ed_to_affine_chunked(p(E), p(xy), p(aok), C.c_size_t(64), c)
+        assert np.array_equal(aok, wok) and np.array_equal(xy, wxy) and not wok[2] and wok[4:24].all(), c
+    eenc, eok = np.empty((64, 4), dtype=np.uint64), np.empty(64, dtype=np.uint8)
+    emul.emul_ed_compress(p(E), p(eenc), p(eok), C.c_size_t(64))
+    wenc2, wok2 = oracle.ed_compress(E)
+    assert np.array_equal(eok, wok2) and wok2[0] and wok2[1] and not wok2[2] and 0 < wok2[3:24].sum() < 21
+    good = wok2.astype(bool)
+    assert np.array_equal(eenc.view(np.uint8).reshape(64, 32)[good], wenc2[good])
     dec = np.empty_like(P)
     emul.emul_ed_decompress(p(enc), p(dec), p(ok), C.c_size_t(n))
     wdec, wok = oracle.ed_decompress(wenc)

@@ -394,6 +394,34 @@ def test_codecs_bulk(eng, oracle):
     assert eq(ok, wok) and eq(enc, wenc)
 
 
+def test_affine_and_compress_edge_rows_and_large_batches(eng, oracle):
+    """Scaled representatives (non-trivial Z), x = 0 points, Z = 0 and off-curve junk through
+    to_affine / compress; batches >= 2^18 take the one-inversion-per-chunk conversion."""
+    E = V.base_multiples(oracle, 512, V.SEED + 64)
+    lam = V.rand_fe_np(512, V.SEED + 65)
+    for c in range(4):
+        E[:, 5 * c:5 * c + 5] = oracle.fe_mul(E[:, 5 * c:5 * c + 5], lam)
+    z, zero = lam[7], np.zeros(5, dtype=np.uint64)
+    E[0] = np.concatenate([zero, z, z, zero])                     # (0, 1)
+    E[1] = np.concatenate([zero, oracle.fe_neg(z[None])[0], z, zero])   # (0, -1)
+    E[2, 10:15] = 0                                               # Z = 0
+    E[3:40] = V.rand_fe_np(37 * 4, V.SEED + 66).reshape(37, 20)   # junk
+    enc, ok = eng.ed_compress(E)
+    wenc, wok = oracle.ed_compress(E)
+    assert eq(ok, wok) and eq(enc, wenc) and wok[0] and wok[1] and not wok[2] and 0 < wok[3:40].sum() < 37
+    xy, aok = eng.ed_to_affine(E)
+    wxy, waok = oracle.ed_to_affine(E)
+    assert eq(aok, waok) and eq(xy, wxy)
+    n = (1 << 18) + 333                                           # chunked conversion, ragged last chunk
+    big = np.tile(E, (n // 512 + 1, 1))[:n].copy()
+    xy, aok = eng.ed_to_affine(big)
+    assert eq(xy[:512], wxy) and eq(aok[:512], waok)
+    assert eq(xy[-845:], np.tile(wxy, (3, 1))[(n - 845) % 512:][:845])
+    assert eq(aok, np.tile(waok, n // 512 + 1)[:n])
+    enc_big, ok_big = eng.ed_compress(big)
+    assert eq(enc_big, np.tile(wenc, (n // 512 + 1, 1))[:n]) and eq(ok_big, np.tile(wok, n // 512 + 1)[:n])
+
+
 def test_ristretto_roundtrip_mul(eng, oracle):
     """config 4 shape: decompress -> scalar-mul -> compress, with ~1% invalid encodings."""
     n = 2048 + 5
