@@ -56,3 +56,19 @@ def test_no_cpu_fallback_and_no_oracle_linkage(lib):
             if f.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "zc_ref" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_rust_shim_binds_the_whole_abi():
+    """integration/rust/zerocaf-hip (source only: no Rust toolchain here) declares every entry
+    point of the header -- ffi.rs is generated from it -- and its safe layer calls each one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    ffi = open(gen.OUT).read()
+    assert ffi == gen.render(), "run tools/gen_rust_ffi.py"
+    declared = set(re.findall(r"pub fn (zc_[a-z0-9_]+)\(", ffi))
+    assert declared == set(declared_symbols())
+    shim = open(os.path.join(os.path.dirname(gen.OUT), "lib.rs")).read()
+    used = set(re.findall(r"ffi::(zc_[a-z0-9_]+)", shim))
+    assert used == declared, sorted(declared - used)
