@@ -13,22 +13,45 @@ struct pt {
     fe X, Y, Z, T;
 };
 
-// fixed exponents, read through the scalar cache (wave-uniform loads)
-__device__ __constant__ u32 ZC_EXP_INV[8] = {ModP::EXP_INV[0], ModP::EXP_INV[1], ModP::EXP_INV[2], ModP::EXP_INV[3],
-                                             ModP::EXP_INV[4], ModP::EXP_INV[5], ModP::EXP_INV[6], ModP::EXP_INV[7]};
-__device__ __constant__ u32 ZC_EXP_P58[8] = {ModP::EXP_P58[0], ModP::EXP_P58[1], ModP::EXP_P58[2], ModP::EXP_P58[3],
-                                             ModP::EXP_P58[4], ModP::EXP_P58[5], ModP::EXP_P58[6], ModP::EXP_P58[7]};
-
-// a^e, e = 2^(nbits-1) + ..., fixed schedule (left-to-right binary, uniform branches)
-ZC_DI fe fp_pow(const fe& a, const u32* __restrict__ e, int nbits)
+// Fixed exponents as sliding-window programs (window 3: a, a^3, a^5, a^7), generated and
+// checked by gen_constants.py; read through the scalar cache (wave-uniform loads).
+// entry = nsq | idx << 8: acc <- acc^(2^nsq) * a^(2 idx + 1), idx 255 = squarings only.
+template <int N>
+struct exp_program {
+    u32 e[N];
+};
+template <int N>
+constexpr exp_program<N> make_program(const u32 (&src)[N])
 {
-    fe acc = a;
-    for (int i = nbits - 2; i >= 0; i--) {
-        acc = mont_sqr<FP>(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) acc = mont_mul<FP>(acc, a);
+    exp_program<N> p{};
+    for (int i = 0; i < N; i++) p.e[i] = src[i];
+    return p;
+}
+__device__ __constant__ exp_program<ModP::PROG_INV_LEN> ZC_PROG_INV = make_program(ModP::PROG_INV);
+__device__ __constant__ exp_program<ModP::PROG_P58_LEN> ZC_PROG_P58 = make_program(ModP::PROG_P58);
+
+// a^e on a fixed schedule (uniform branches): same value as any other evaluation order.
+ZC_DI fe fp_pow_program(const fe& a, const u32* __restrict__ prog, int len)
+{
+    const fe a2 = mont_sqr<FP>(a);
+    const fe a3 = mont_mul<FP>(a2, a), a5 = mont_mul<FP>(a3, a2), a7 = mont_mul<FP>(a5, a2);
+    const u32 first = prog[0] >> 8;
+    fe acc = first == 0 ? a : first == 1 ? a3 : first == 2 ? a5 : a7;
+    for (int k = 1; k < len; k++) {
+        const u32 entry = prog[k];
+        for (u32 s = entry & 0xFF; s > 0; s--) acc = mont_sqr<FP>(acc);
+        switch (entry >> 8) {
+            case 0: acc = mont_mul<FP>(acc, a); break;
+            case 1: acc = mont_mul<FP>(acc, a3); break;
+            case 2: acc = mont_mul<FP>(acc, a5); break;
+            case 3: acc = mont_mul<FP>(acc, a7); break;
+            default: break;
+        }
     }
     return acc;
 }
+ZC_DI fe fp_pow_inv(const fe& a) { return fp_pow_program(a, ZC_PROG_INV.e, ModP::PROG_INV_LEN); }      // a^(p-2)
+ZC_DI fe fp_pow_p58(const fe& a) { return fp_pow_program(a, ZC_PROG_P58.e, ModP::PROG_P58_LEN); }      // a^((p-5)/8)
 
 ZC_DI fe fp_mul(const fe& a, const fe& b) { return mont_mul<FP>(a, b); }
 ZC_DI fe fp_sqr(const fe& a) { return mont_sqr<FP>(a); }
@@ -40,7 +63,7 @@ ZC_DI bool fp_is_zero(const fe& a) { return fe_is_zero_canon(fp_canon(a)); }
 ZC_DI bool fp_eq(const fe& a, const fe& b) { return fp_is_zero(fp_sub(a, b)); }
 
 // a^(p-2): same value as the reference's Savas-Koc inverse (field.rs:854-925) for a != 0
-ZC_DI fe fp_invert(const fe& a) { return fp_pow(a, ZC_EXP_INV, ModP::EXP_INV_BITS); }
+ZC_DI fe fp_invert(const fe& a) { return fp_pow_inv(a); }
 
 // |x| by the reference's sign rule: negate when canonical value > (p-1)/2
 // (field.rs:552-557 + subtle conditional_negate).  Returns R-class Montgomery value.
@@ -62,7 +85,7 @@ ZC_DI bool fp_sqrt_ratio_i(fe& out, const fe& u, const fe& v)
     const fe v3 = fp_mul(v2, v);
     const fe v7 = fp_mul(fp_sqr(v3), v);
     const fe uv3 = fp_mul(u, v3);
-    fe r = fp_mul(uv3, fp_pow(fp_mul(u, v7), ZC_EXP_P58, ModP::EXP_P58_BITS));
+    fe r = fp_mul(uv3, fp_pow_p58(fp_mul(u, v7)));
     const fe check = fp_mul(v, fp_sqr(r));
     const fe ui = fp_mul(u, i_m);
     const fe cc = fp_canon(check), uc = fp_canon(u);
@@ -79,7 +102,7 @@ ZC_DI bool fp_sqrt_ratio_i(fe& out, const fe& u, const fe& v)
 // x = a^((q+1)/2), times 6^q when a^q == -1; None when a^q is not +-1.  a R-class.
 ZC_DI bool fp_ts_sqrt(fe& x, const fe& a)
 {
-    const fe w = fp_pow(a, ZC_EXP_P58, ModP::EXP_P58_BITS);      // a^((q-1)/2)
+    const fe w = fp_pow_p58(a);      // a^((q-1)/2)
     const fe x0 = fp_mul(a, w);                                   // a^((q+1)/2)
     const fe t = fp_canon(fp_mul(x0, w));                         // a^q, plain canonical
     fe one = fe_zero();
@@ -164,7 +187,7 @@ ZC_DI fe fp_pow_var(const fe& a, const fe& e)
 // legendre_symbol (field.rs:703-706): Choice(0) iff a^((p-1)/2) == -1 (so 0 maps to 1)
 ZC_DI bool fp_legendre(const fe& a)
 {
-    const fe w = fp_pow(a, ZC_EXP_P58, ModP::EXP_P58_BITS);      // a^((q-1)/2)
+    const fe w = fp_pow_p58(a);      // a^((q-1)/2)
     const fe t = fp_mul(fp_mul(a, w), w);                         // a^q
     fe one = fe_zero();
     one.v[0] = 1;
@@ -698,7 +721,7 @@ ZC_DI bool ed_compress(u64 (&w)[4], const pt& p)
     const fe v = fe_reduce<FP>(fe_add(fp_mul(fe_const<FP>(ModP::D_M), Y2), Z2));
     const fe Z4 = fp_sqr(Z2);
     const fe v2 = fp_sqr(v), v3 = fp_mul(v2, v), v4 = fp_sqr(v2);
-    const fe E = fp_pow(fp_mul(fp_mul(u, fp_mul(v4, v3)), fp_sqr(Z4)), ZC_EXP_P58, ModP::EXP_P58_BITS);
+    const fe E = fp_pow_p58(fp_mul(fp_mul(u, fp_mul(v4, v3)), fp_sqr(Z4)));
     const fe x0 = fp_mul(fp_mul(fp_mul(u, v3), Z4), E);
     const fe check = fp_mul(v, fp_sqr(x0));
     const bool t_is_one = fe_eq_canon(fp_canon(check), fp_canon(u));
@@ -723,7 +746,7 @@ ZC_DI bool fp_ts_sqrt_ratio(fe& x, const fe& u, const fe& v)
 {
     const fe v3 = fp_mul(fp_sqr(v), v);
     const fe v7 = fp_mul(fp_sqr(v3), v);
-    const fe x0 = fp_mul(fp_mul(u, v3), fp_pow(fp_mul(u, v7), ZC_EXP_P58, ModP::EXP_P58_BITS));
+    const fe x0 = fp_mul(fp_mul(u, v3), fp_pow_p58(fp_mul(u, v7)));
     const fe check = fp_mul(v, fp_sqr(x0));
     const bool t_is_one = fe_eq_canon(fp_canon(check), fp_canon(u));          // also u == 0 -> Some(0)
     const bool t_is_m1 = fe_is_zero_canon(fp_canon(fe_add(check, u)));
