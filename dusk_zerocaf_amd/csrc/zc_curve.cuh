@@ -719,15 +719,22 @@ ZC_DI bool ed_compress(u64 (&w)[4], const pt& p)
     const fe Y2 = fp_sqr(p.Y), Z2 = fp_sqr(p.Z);
     const fe u = fe_reduce<FP>(fp_sub(Y2, Z2));
     const fe v = fe_reduce<FP>(fe_add(fp_mul(fe_const<FP>(ModP::D_M), Y2), Z2));
-    const fe Z4 = fp_sqr(Z2);
-    const fe v2 = fp_sqr(v), v3 = fp_mul(v2, v), v4 = fp_sqr(v2);
-    const fe E = fp_pow_p58(fp_mul(fp_mul(u, fp_mul(v4, v3)), fp_sqr(Z4)));
-    const fe x0 = fp_mul(fp_mul(fp_mul(u, v3), Z4), E);
+    // everything that outlives the exponentiation is folded into two products first
+    fe w1, w2, base;
+    {
+        const fe Z4 = fp_sqr(Z2);
+        const fe v2 = fp_sqr(v), v3 = fp_mul(v2, v), v4 = fp_sqr(v2);
+        w1 = fp_mul(fp_mul(u, v3), Z4);                               // x0 = w1 E
+        w2 = fp_mul(v4, fp_mul(Z2, p.Z));                             // 1/Z = t E x0 w2
+        base = fp_mul(fp_mul(w1, v4), Z4);                            // u v^7 Z^8
+    }
+    const fe E = fp_pow_p58(base);
+    const fe x0 = fp_mul(w1, E);
     const fe check = fp_mul(v, fp_sqr(x0));
     const bool t_is_one = fe_eq_canon(fp_canon(check), fp_canon(u));
     const bool t_is_m1 = fe_is_zero_canon(fp_canon(fe_add(check, u)));
     const fe r = fe_select(t_is_one, x0, fp_mul(x0, fe_const<FP>(ModP::SIX_POW_Q_M)));
-    fe zinv = fp_mul(fp_mul(fp_mul(E, x0), v4), fp_mul(Z2, p.Z));
+    fe zinv = fp_mul(fp_mul(E, x0), w2);
     zinv = fe_select(t_is_one, zinv, fe_reduce<FP>(fp_neg(zinv)));
     fe y = fp_mul(p.Y, zinv);
     const bool u_zero = fp_is_zero(u);

@@ -7,6 +7,8 @@
 namespace zc {
 
 #define ZC_KERNEL extern "C" __global__ __launch_bounds__(256)
+// same, with the register budget capped so that two waves fit on a SIMD
+#define ZC_KERNEL_2W extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 constexpr int ZC_BLOCK = 256;
 
 ZC_DI size_t gid() { return (size_t)blockIdx.x * ZC_BLOCK + threadIdx.x; }
@@ -695,7 +697,7 @@ ZC_KERNEL void k_ed_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
     if (i >= n) return;
     eq[i] = ed_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
 }
-ZC_KERNEL void k_ed_compress(const u64* p, uint8_t* out, uint8_t* ok, size_t n)
+ZC_KERNEL_2W void k_ed_compress(const u64* p, uint8_t* out, uint8_t* ok, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
@@ -744,7 +746,7 @@ ZC_KERNEL void k_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
     eq[i] = ris_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
 }
 // fused config-4 path: 32 B in -> registers -> 32 B out; the point never touches HBM
-ZC_KERNEL void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, const u32* idx, size_t n)
+ZC_KERNEL_2W void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, const u32* idx, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
     __shared__ u32 skey[ZC_BLOCK];
@@ -811,7 +813,7 @@ ZC_KERNEL void k_ris_elligator(const u64* r0, u64* out, size_t n)
     pt_store(out + 20 * i, ris_elligator(fe_load_mont<FP>(r0 + 5 * i)));
 }
 // from_uniform_bytes (ristretto.rs:493-507): two Elligator maps, one addition
-ZC_KERNEL void k_ris_from_uniform_bytes(const uint8_t* in, u64* out, size_t n)
+ZC_KERNEL_2W void k_ris_from_uniform_bytes(const uint8_t* in, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
