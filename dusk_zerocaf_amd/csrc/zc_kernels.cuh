@@ -8,6 +8,7 @@ namespace zc {
 
 #define ZC_KERNEL extern "C" __global__ __launch_bounds__(256)
 // same, with the register budget capped so that two waves fit on a SIMD
+#define ZC_KERNEL_3W extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 #define ZC_KERNEL_2W extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 constexpr int ZC_BLOCK = 256;
 
@@ -553,7 +554,7 @@ ZC_KERNEL void k_ed_scalar_mul_fast(const u64* p, const u64* k, size_t k_stride,
 }
 // fused config-4 path on the fast core: the boundary is bytes in / bytes out, and a Ristretto
 // encoding depends only on the group element, so the outputs stay bit-identical to the reference
-ZC_KERNEL void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, u32* table, size_t n)
+ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, u32* table, size_t n)
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
     const int tid = threadIdx.x;
