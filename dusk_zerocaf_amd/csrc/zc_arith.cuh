@@ -170,6 +170,26 @@ ZC_DI fe fe_sub(const fe& a, const fe& b)
     fe_carry(r);
     return r;
 }
+// (a - b) / 2 mod N, normalized: a - b + 4N, plus N when that is odd (N is odd, and the parity
+// of the whole value is the parity of limb 0), then one exact right shift.  a, b < 2N with
+// limbs 0..7 < 2^29 (products of operands below 8N): result < 3.5N, top limb below BIAS[8], so it
+// may stand on either side of a later fe_sub.
+template <class F>
+ZC_DI fe fe_sub_half(const fe& a, const fe& b)
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
+    const u32 odd = 0u - (r.v[0] & 1u);
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        if (F::N[i] != 0) r.v[i] += F::N[i] & odd;
+    fe_carry(r);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (r.v[i] >> 1) | ((r.v[i + 1] & 1u) << 28);
+    r.v[8] >>= 1;
+    return r;
+}
 template <class F>
 ZC_DI fe fe_neg(const fe& b)
 {

@@ -213,18 +213,23 @@ ZC_DI pt pt_select(bool c, const pt& a, const pt& b)
     r.T = fe_select(c, a.T, b.T);
     return r;
 }
-// HWCD'08 unified addition, a = -1 (edwards.rs:465-489): 10 mul.  Inputs R-class.
+// HWCD'08 unified addition, a = -1 (edwards.rs:465-489).  The reference forms
+//   A = X1 X2, B = Y1 Y2, E = (X1+Y1)(X2+Y2) - A - B = X1 Y2 + Y1 X2, H = B + A
+// with three multiplications; the same two field values come out of two:
+//   M = (Y1-X1)(Y2-X2) = H - E,  P = (Y1+X1)(Y2+X2) = H + E,  E = (P - M)/2 (exact halving),
+//   H = P - E
+// so a step costs 9 multiplications and X3 = E F, Y3 = G H, Z3 = F G, T3 = E H are the
+// reference's values limb for limb.  Inputs R-class.
 ZC_DI pt pt_add(const pt& p, const pt& q)
 {
-    const fe A = fp_mul(p.X, q.X);
-    const fe B = fp_mul(p.Y, q.Y);
+    const fe M = fp_mul(fp_sub(p.Y, p.X), fp_sub(q.Y, q.X));          // operands < 7N: M < 2N
+    const fe P = fp_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));          // operands < 6N: P < 2N
     const fe C = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), p.T), q.T);
     const fe D = fp_mul(p.Z, q.Z);
-    fe E = fp_mul(fe_add(p.X, p.Y), fe_add(q.X, q.Y));
-    E = fp_sub(fp_sub(E, A), B);
+    const fe E = fe_sub_half<FP>(P, M);
+    const fe H = fp_sub(P, E);
     const fe F = fp_sub(D, C);
     const fe G = fe_add(D, C);
-    const fe H = fe_add(B, A);
     pt r;
     r.X = fp_mul(E, F);
     r.Y = fp_mul(G, H);
