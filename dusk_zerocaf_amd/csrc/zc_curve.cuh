@@ -468,13 +468,17 @@ ZC_DI niels niels_load(const u32* __restrict__ c)
     q.t2d = unpack256(v[6], v[7]);
     return q;
 }
-// p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square)
+// p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square).
+// ILP selects the multiplier with independent column chains (mont_mul_ilp) for memory-latency
+// bound callers.
+template <bool ILP = false>
 ZC_DI pt pt_add_cached(const pt& p, const niels& q)
 {
-    const fe A = fp_mul(fp_sub(p.Y, p.X), q.ymx);
-    const fe B = fp_mul(fe_add(p.Y, p.X), q.ypx);
-    const fe C = fp_mul(p.T, q.t2d);
-    const fe ZZ = fp_mul(p.Z, q.z);
+    auto mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
+    const fe A = mul(fp_sub(p.Y, p.X), q.ymx);
+    const fe B = mul(fe_add(p.Y, p.X), q.ypx);
+    const fe C = mul(p.T, q.t2d);
+    const fe ZZ = mul(p.Z, q.z);
     fe D = fe_add(ZZ, ZZ);
     fe_carry(D);
     const fe E = fp_sub(B, A);
@@ -482,10 +486,10 @@ ZC_DI pt pt_add_cached(const pt& p, const niels& q)
     const fe G = fe_add(D, C);
     const fe H = fe_add(B, A);
     pt r;
-    r.X = fp_mul(E, F);
-    r.Y = fp_mul(G, H);
-    r.Z = fp_mul(F, G);
-    r.T = fp_mul(E, H);
+    r.X = mul(E, F);
+    r.Y = mul(G, H);
+    r.Z = mul(F, G);
+    r.T = mul(E, H);
     return r;
 }
 

@@ -115,7 +115,7 @@ ZC_KERNEL void k_msm_accumulate(const u32* cached, const u32* vals, const u32* s
                 inext = (e + 2 < hi) ? vals[e + 2] : 0;
                 niels nxt = cur;
                 if (e + 1 < hi) nxt = niels_load(cached + 32 * (size_t)iload);
-                acc = pt_add_cached(acc, cur);
+                acc = pt_add_cached<true>(acc, cur);
                 cur = nxt;
             }
         }
