@@ -46,6 +46,14 @@ namespace zc {
 #else
 #define ZC_PIN(x) asm("" : "+r"(x))
 #endif
+// Invariant checks of the lazy-reduction scheme: compiled only into the host emulation of the
+// test tier (tests/emul, -DZC_CHECK_BOUNDS); nothing on the device.
+#if defined(ZC_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" void zc_bound_fail(const char* what, int line);
+#define ZC_ASSERT(cond) do { if (!(cond)) zc_bound_fail(#cond, __LINE__); } while (0)
+#else
+#define ZC_ASSERT(cond) do { } while (0)
+#endif
 constexpr u32 M29 = 0x1fffffffu;
 constexpr u64 M52 = (1ull << 52) - 1;
 
@@ -138,6 +146,8 @@ ZC_DI void mont_reduce_cols(fe& r, u64 (&t)[18])
 template <class F>
 ZC_DI fe mont_mul(const fe& a, const fe& b)
 {
+    for (int i = 0; i < 9; i++) ZC_ASSERT(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));   // lazy: columns < 2^64
+    ZC_ASSERT((u64)(a.v[8] + 1) * (b.v[8] + 1) <= (1ull << 50));                          // a b < 2 R N: result < 3N
 #define ZC_MUL_PRODUCTS(k)                                                       \
     _Pragma("unroll") for (int i = 0; i < 9; i++)                                \
         if (k - i >= 0 && k - i < 9) {                                           \
@@ -152,6 +162,8 @@ ZC_DI fe mont_mul(const fe& a, const fe& b)
 template <class F>
 ZC_DI fe mont_sqr(const fe& a)
 {
+    for (int i = 0; i < 9; i++) ZC_ASSERT(a.v[i] < (1u << 30));
+    ZC_ASSERT(a.v[8] < (1u << 25));
     u32 d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;   // limbs < 2^30 -> < 2^31
@@ -177,6 +189,8 @@ ZC_DI fe mont_sqr(const fe& a)
 template <class F>
 ZC_DI fe mont_mul_ilp(const fe& a, const fe& b)
 {
+    for (int i = 0; i < 9; i++) ZC_ASSERT(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));
+    ZC_ASSERT((u64)(a.v[8] + 1) * (b.v[8] + 1) <= (1ull << 50));
     u64 t[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) t[k] = 0;
@@ -227,6 +241,7 @@ ZC_DI fe fe_add(const fe& a, const fe& b)
 template <class F>
 ZC_DI fe fe_sub(const fe& a, const fe& b)
 {
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i] && a.v[i] < (1u << 31));
     fe r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
@@ -240,6 +255,8 @@ ZC_DI fe fe_sub(const fe& a, const fe& b)
 template <class F>
 ZC_DI fe fe_sub_half(const fe& a, const fe& b)
 {
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i] && a.v[i] < (1u << 30));
+    ZC_ASSERT(a.v[8] < (2u << F::TOPSHIFT) + 2 && b.v[8] < (2u << F::TOPSHIFT) + 2);      // a, b < 2N
     fe r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
@@ -251,11 +268,13 @@ ZC_DI fe fe_sub_half(const fe& a, const fe& b)
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = (r.v[i] >> 1) | ((r.v[i + 1] & 1u) << 28);
     r.v[8] >>= 1;
+    ZC_ASSERT(r.v[8] <= F::BIAS[8]);
     return r;
 }
 template <class F>
 ZC_DI fe fe_neg(const fe& b)
 {
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i]);
     fe r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.v[i] = F::BIAS[i] - b.v[i];

@@ -6,7 +6,16 @@
 // dusk_zerocaf_amd/: the product path has no CPU fallback.
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include "../../dusk_zerocaf_amd/csrc/zc_curve.cuh"
+
+// -DZC_CHECK_BOUNDS build: every lazy-reduction precondition in zc_arith.cuh is asserted
+extern "C" void zc_bound_fail(const char* what, int line)
+{
+    std::fprintf(stderr, "zc_arith.cuh:%d: bound violated: %s\n", line, what);
+    std::abort();
+}
 
 using namespace zc;
 
@@ -132,6 +141,18 @@ void emul_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 extern "C" void emul_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
 {
     for (size_t lo = 0; lo < n; lo += (size_t)c) fe_invert_chunk(a, out, ok, n, lo, c);
+}
+// the MSM bucket accumulation's inner loop (zc_msm.cuh): cached-operand additions on the
+// independent-chain multiplier, through the packed 128-byte record
+extern "C" void emul_bucket_sum(const u64* pts, size_t n, u64* out)
+{
+    pt acc = pt_identity();
+    for (size_t i = 0; i < n; i++) {
+        u32 rec[32];
+        niels_store(rec, niels_from_pt(pt_load(pts + 20 * i)));
+        acc = pt_add_cached<true>(acc, niels_load(rec));
+    }
+    pt_store(out, acc);
 }
 extern "C" void emul_ed_to_affine_chunked(const u64* pts, u64* xy, uint8_t* ok, size_t n, int c)
 {
