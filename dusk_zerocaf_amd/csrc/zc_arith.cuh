@@ -61,6 +61,19 @@ struct fe {
     u32 v[9];
 };
 
+// 9 products of the largest limbs + 6 reduction terms + carry stay below 2^64 (checked builds only)
+#if defined(ZC_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+inline bool fe_columns_fit(const fe& a, const fe& b)
+{
+    u64 ma = 0, mb = 0;
+    for (int i = 0; i < 9; i++) {
+        if (a.v[i] > ma) ma = a.v[i];
+        if (b.v[i] > mb) mb = b.v[i];
+    }
+    const unsigned __int128 worst = (unsigned __int128)9 * ma * mb + ((unsigned __int128)3 << 59);
+    return (worst >> 64) == 0;
+}
+#endif
 template <class F>
 ZC_DI fe fe_const(const u32 (&c)[9])
 {
@@ -146,7 +159,7 @@ ZC_DI void mont_reduce_cols(fe& r, u64 (&t)[18])
 template <class F>
 ZC_DI fe mont_mul(const fe& a, const fe& b)
 {
-    for (int i = 0; i < 9; i++) ZC_ASSERT(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));   // lazy: columns < 2^64
+    ZC_ASSERT(fe_columns_fit(a, b));                                                      // columns < 2^64
     ZC_ASSERT((u64)(a.v[8] + 1) * (b.v[8] + 1) <= (1ull << 50));                          // a b < 2 R N: result < 3N
 #define ZC_MUL_PRODUCTS(k)                                                       \
     _Pragma("unroll") for (int i = 0; i < 9; i++)                                \
@@ -189,7 +202,7 @@ ZC_DI fe mont_sqr(const fe& a)
 template <class F>
 ZC_DI fe mont_mul_ilp(const fe& a, const fe& b)
 {
-    for (int i = 0; i < 9; i++) ZC_ASSERT(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));
+    ZC_ASSERT(fe_columns_fit(a, b));
     ZC_ASSERT((u64)(a.v[8] + 1) * (b.v[8] + 1) <= (1ull << 50));
     u64 t[18];
 #pragma unroll
@@ -246,6 +259,17 @@ ZC_DI fe fe_sub(const fe& a, const fe& b)
 #pragma unroll
     for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
     fe_carry(r);
+    return r;
+}
+// a - b + 4N with NO carry pass: limbs < 2^29 + 2^30.  Only as a multiplier operand whose partner
+// has limbs < 2^30 (9 * 1.5 * 2^60 + reduction terms < 2^64).  a: limbs < 2^29; b R-class.
+template <class F>
+ZC_DI fe fe_sub_lazy(const fe& a, const fe& b)
+{
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i] && a.v[i] < (1u << 29) + (i == 8 ? (1u << 29) : 0));
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
     return r;
 }
 // (a - b) / 2 mod N, normalized: a - b + 4N, plus N when that is odd (N is odd, and the parity

@@ -237,6 +237,60 @@ ZC_DI pt pt_add(const pt& p, const pt& q)
     r.T = fp_mul(E, H);
     return r;
 }
+// The scalar-multiplication loop keeps its two points as (Y-X, Y+X, Z, T): the unified addition
+// consumes exactly these combinations of BOTH operands, so forming them once per result instead
+// of once per use saves a subtraction and an addition per step.  F and H skip the carry pass
+// (fe_sub_lazy): their partners G = D + C and E have limbs < 2^30.  X and Y come back at the end
+// through one multiplication by 1/2 each; every field value is the reference's.
+struct ptm {
+    fe Ym, Yp, Z, T;     // Y - X normalized (< 7N), Y + X lazy (< 6N), Z and T R-class
+};
+ZC_DI ptm ptm_from_pt(const pt& p)
+{
+    ptm r;
+    r.Ym = fp_sub(p.Y, p.X);
+    r.Yp = fe_add(p.Y, p.X);
+    r.Z = p.Z;
+    r.T = p.T;
+    return r;
+}
+ZC_DI ptm ptm_select(bool c, const ptm& a, const ptm& b)
+{
+    ptm r;
+    r.Ym = fe_select(c, a.Ym, b.Ym);
+    r.Yp = fe_select(c, a.Yp, b.Yp);
+    r.Z = fe_select(c, a.Z, b.Z);
+    r.T = fe_select(c, a.T, b.T);
+    return r;
+}
+ZC_DI ptm ptm_add(const ptm& p, const ptm& q)          // same values as pt_add
+{
+    const fe M = fp_mul(p.Ym, q.Ym);
+    const fe P = fp_mul(p.Yp, q.Yp);
+    const fe C = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), p.T), q.T);
+    const fe D = fp_mul(p.Z, q.Z);
+    const fe E = fe_sub_half<FP>(P, M);
+    const fe H = fe_sub_lazy<FP>(P, E);
+    const fe F = fe_sub_lazy<FP>(D, C);
+    const fe G = fe_add(D, C);
+    const fe X3 = fp_mul(E, F), Y3 = fp_mul(G, H);
+    ptm r;
+    r.Ym = fp_sub(Y3, X3);
+    r.Yp = fe_add(Y3, X3);
+    r.Z = fp_mul(F, G);
+    r.T = fp_mul(E, H);
+    return r;
+}
+ZC_DI pt ptm_to_pt(const ptm& p)
+{
+    const fe half = fe_const<FP>(ModP::INV2_M);
+    pt r;
+    r.X = fp_mul(fp_sub(p.Yp, fe_reduce<FP>(p.Ym)), half);     // Ym < 7N is no subtrahend as it stands
+    r.Y = fp_mul(fe_add(p.Yp, p.Ym), half);
+    r.Z = p.Z;
+    r.T = p.T;
+    return r;
+}
 ZC_DI pt pt_neg(const pt& p)                                      // edwards.rs:440-455
 {
     pt r;
@@ -291,14 +345,14 @@ ZC_DI void scalar_to_words(u32* __restrict__ sk, int stride, const u64 (&l)[5], 
 // max_lane(bitlen - 1 + popcount) formula evaluations.
 ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int stride, int nbits)
 {
-    pt N = P, Q = pt_identity();
+    ptm N = ptm_from_pt(P), Q = ptm_from_pt(pt_identity());
     int pos = 0;
     u32 cur = sk[0];
     bool pend = (cur & 1) != 0;
     bool active = nbits > 0;
     while (active) {
-        const pt lhs = pt_select(pend, Q, N);
-        const pt r = pt_add(lhs, N);
+        const ptm lhs = ptm_select(pend, Q, N);
+        const ptm r = ptm_add(lhs, N);
         if (pend) {
             Q = r;
             pend = false;
@@ -310,7 +364,7 @@ ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int stride,
             pend = ((cur >> (pos & 31)) & 1) != 0;
         }
     }
-    return Q;
+    return ptm_to_pt(Q);
 }
 
 // Left-to-right variants of the reference, same unified-step machinery with
