@@ -224,25 +224,27 @@ def main():
         except Exception:
             pass
     ub = os.path.join(ROOT, "profiles", "r01_ubench.json")
-    if args.workload == "scalar_mul" and args.mode == "strict" and os.path.exists(ub):
+    mix = os.path.join(ROOT, "profiles", "r01_isa_mix.json")
+    if args.workload == "scalar_mul" and args.mode == "strict" and os.path.exists(ub) and os.path.exists(mix):
         try:
-            u = json.load(open(ub))
-            mad_peak = float(u["v_mad_u64_u32_lane_ops_per_s"])
-            alu_peak = float(u["v_add_u32_lane_ops_per_s"])
+            u, m = json.load(open(ub)), json.load(open(mix))
+            mad_peak = float(u["v_mad_u64_u32_lane_ops_per_s"])          # lane-ops/s, all CUs, tools/ubench
             insts = float(json.load(open(pmc))["scalar_mul_valu_insts_per_launch"]) * n / (1 << 20)
-            # instruction mix of one unified step (ISA histogram of k_ed_scalar_mul): 10 Montgomery
-            # multiplications x (135 v_mad_u64_u32 + 9 v_mul_lo_u32 + 32 64-bit shift/add), the
-            # rest 32-bit ALU; ubench rates for the slow class (~5 cycles) and the fast class (2.5)
-            heavy = 10 * (135 + 9 + 32) / 2420.0
-            t_min = insts * 64 * (heavy / mad_peak + (1 - heavy) / alu_peak)
+            # The step loop's ISA (tools/isa_mix.py): 9 Montgomery multiplications x (135 v_mad_u64_u32 +
+            # 9 v_mul_lo_u32 + 16 v_lshrrev_b64).  These run at the multiplier's rate (~5 cycles per
+            # wave-instruction per SIMD); the 32-bit ALU ops in between were measured not to cost issue
+            # time (removing ~100 of them per step changed the kernel time by 0.3 %).
+            share = m["multiplier_rate_class_per_step"] / float(m["valu_per_step"])
+            t_mult = insts * share * 64 / mad_peak
             roofline["valu"] = {
-                "note": "this kernel is integer-VALU issue bound, not HBM bound (0.2% of HBM peak is expected); "
-                        "issue_bound_ms = PMC instruction count x microbenchmarked issue rates, >1.0 means the "
-                        "kernel issues faster than the dependent-chain microbenchmark",
-                "valu_wave_insts_per_launch": insts, "mad_class_fraction": round(heavy, 3),
-                "v_mad_u64_u32_peak_lane_ops_per_s": mad_peak, "alu32_peak_lane_ops_per_s": alu_peak,
-                "issue_bound_ms": round(t_min * 1e3, 3),
-                "frac_of_issue_bound": round(t_min / kern_avg_s, 4)}
+                "note": "integer-VALU bound, not HBM bound (0.2% of HBM peak is expected): multiplier_bound_ms = "
+                        "PMC SQ_INSTS_VALU x share of multiplier-rate instructions in the step loop (ISA histogram) "
+                        "/ microbenchmarked v_mad_u64_u32 throughput of the whole chip",
+                "valu_wave_insts_per_launch": insts, "multiplier_rate_share": round(share, 4),
+                "per_step": {"valu": m["valu_per_step"], "multiplier_rate": m["multiplier_rate_class_per_step"]},
+                "v_mad_u64_u32_peak_lane_ops_per_s": mad_peak,
+                "multiplier_bound_ms": round(t_mult * 1e3, 3),
+                "frac_of_multiplier_peak": round(t_mult / kern_avg_s, 4)}
         except Exception:
             pass
 
