@@ -8,7 +8,8 @@
 //                       one 128-byte cache line per point
 //   4. k_msm_counts + rocPRIM sort of the bucket ids by population (descending), then
 //      k_msm_accumulate: one lane per bucket, lanes of a wave get equally full buckets; each
-//      point costs one 8-multiplication a = -1 addition against the cached form
+//      point costs one 8-multiplication a = -1 addition against the cached form; the next
+//      record is prefetched straight into LDS (global_load_lds), four waves per SIMD
 //   5. k_msm_segments : running-sum reduction of each window in segments of SEG buckets
 //                       (sum_seg = sum (d - lo + 1) B_d, acc_seg = sum B_d)
 //   6. existing kernels: (lo - 1) * acc_seg via k_ed_scalar_mul, k_ed_add, k_ed_fold_pairs down
@@ -96,31 +97,50 @@ ZC_KERNEL void k_msm_counts(const u32* start, const u32* end, u32* count, u32* i
 
 // buckets[b] = sum of the points whose (window, digit) == b.  `order` lists the bucket ids by
 // descending population so the 64 lanes of a wave run (almost) the same trip count.
-ZC_KERNEL void k_msm_accumulate(const u32* cached, const u32* vals, const u32* start, const u32* end, const u32* order,
-                                u64* buckets, size_t nbuckets, int c)
+// The (random) 128-byte gather of point e+1 is in flight while point e is being added, and it
+// lands in LDS, not in registers: `global_load_lds_dwordx4` copies 16 bytes per lane straight into
+// the wave's staging area (piece j of all 64 lanes contiguous: M0 = base + j KB), so the prefetch
+// holds no VGPRs and the kernel fits four waves per SIMD (32 KB of LDS per block, 4 blocks per CU).
+// A lane reads and overwrites only its own slots: lgkmcnt(0) before the next copy is issued,
+// vmcnt(0) before the slots are read.
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+void k_msm_accumulate(const u32* cached, const u32* vals, const u32* start, const u32* end, const u32* order,
+                      u64* buckets, size_t nbuckets, int c)
 {
+    __shared__ uint4 stage[8 * ZC_BLOCK];
+    const int lane = threadIdx.x & 63;
+    uint4* base = stage + (threadIdx.x >> 6) * (8 * 64);
     const size_t j = gid();
-    if (j >= nbuckets) return;
-    const size_t b = order[j];
-    pt acc = pt_identity();
-    if ((b & ((1u << c) - 1)) != 0) {
-        // software pipeline: the (random) 144-byte gather of point e+1 and the index of point
-        // e+2 are in flight while point e is being added
-        const u32 lo = start[b], hi = end[b];
-        if (lo < hi) {
-            niels cur = niels_load(cached + 32 * (size_t)vals[lo]);
-            u32 inext = (lo + 1 < hi) ? vals[lo + 1] : 0;
-            for (u32 e = lo; e < hi; e++) {
-                const u32 iload = inext;
-                inext = (e + 2 < hi) ? vals[e + 2] : 0;
-                niels nxt = cur;
-                if (e + 1 < hi) nxt = niels_load(cached + 32 * (size_t)iload);
-                acc = pt_add_cached<true>(acc, cur);
-                cur = nxt;
-            }
-        }
+    const bool valid = j < nbuckets;
+    const size_t b = valid ? order[j] : 0;
+    u32 lo = 0, hi = 0;
+    if (valid && (b & ((1u << c) - 1)) != 0) {
+        lo = start[b];
+        hi = end[b];
     }
-    pt_store(buckets + 20 * b, acc);
+    auto fetch = [&](u32 idx) {
+        const uint4* src = reinterpret_cast<const uint4*>(cached + 32 * (size_t)idx);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q),
+                                             (__attribute__((address_space(3))) void*)(base + q * 64), 16, 0, 0);
+    };
+    pt acc = pt_identity();
+    if (lo < hi) fetch(vals[lo]);
+    u32 inext = (lo + 1 < hi) ? vals[lo + 1] : 0;
+    for (u32 e = lo; e < hi; e++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        niels cur;
+        cur.ymx = unpack256(base[0 * 64 + lane], base[1 * 64 + lane]);
+        cur.ypx = unpack256(base[2 * 64 + lane], base[3 * 64 + lane]);
+        cur.z = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
+        cur.t2d = unpack256(base[6 * 64 + lane], base[7 * 64 + lane]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (e + 1 < hi) fetch(inext);
+        inext = (e + 2 < hi) ? vals[e + 2] : 0;
+        acc = pt_add_cached<true>(acc, cur);
+    }
+    if (valid) pt_store(buckets + 20 * b, acc);
 }
 
 // One lane per segment of MSM_SEG consecutive buckets [lo, lo + SEG) of one window:
