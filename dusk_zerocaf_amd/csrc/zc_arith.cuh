@@ -272,6 +272,38 @@ ZC_DI fe fe_sub_lazy(const fe& a, const fe& b)
     for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]);
     return r;
 }
+// a - b - c + 8N with one carry pass (b, c R-class): normalized, value < a + 8N.
+template <class F>
+ZC_DI fe fe_sub2(const fe& a, const fe& b, const fe& c)
+{
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i] && c.v[i] <= F::BIAS[i] && a.v[i] < (1u << 30));
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]) + (F::BIAS[i] - c.v[i]);
+    fe_carry(r);
+    return r;
+}
+// the same without the carry pass: limbs < 2^29 + 2^31.  Multiplier operand only, and only against
+// a normalized partner (limbs < 2^29): 9 * 2.5 * 2^59 + reduction terms < 2^64.  a: limbs < 2^29.
+template <class F>
+ZC_DI fe fe_sub2_lazy(const fe& a, const fe& b, const fe& c)
+{
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i] && c.v[i] <= F::BIAS[i] && a.v[i] < (1u << 29) + (i == 8 ? (1u << 29) : 0));
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (F::BIAS[i] - b.v[i]) + (F::BIAS[i] - c.v[i]);
+    return r;
+}
+// 4N - b without the carry pass (limbs < 2^30): multiplier operand only.  b R-class.
+template <class F>
+ZC_DI fe fe_neg_lazy(const fe& b)
+{
+    for (int i = 0; i < 9; i++) ZC_ASSERT(b.v[i] <= F::BIAS[i]);
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = F::BIAS[i] - b.v[i];
+    return r;
+}
 // (a - b) / 2 mod N, normalized: a - b + 4N, plus N when that is odd (N is odd, and the parity
 // of the whole value is the parity of limb 0), then one exact right shift.  a, b < 2N with
 // limbs 0..7 < 2^29 (products of operands below 8N): result < 3.5N, top limb below BIAS[8], so it

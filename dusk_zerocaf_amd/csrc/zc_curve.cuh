@@ -502,7 +502,7 @@ ZC_DI niels niels_cond_neg(bool neg, const niels& q)
     r.ymx = fe_select(neg, q.ypx, q.ymx);
     r.ypx = fe_select(neg, q.ymx, q.ypx);
     r.z = q.z;
-    r.t2d = fe_select(neg, fp_neg(q.t2d), q.t2d);          // q.t2d is R-class (a product)
+    r.t2d = fe_select(neg, fe_neg_lazy<FP>(q.t2d), q.t2d);  // q.t2d is R-class (a product); meets the normalized T
     return r;
 }
 ZC_DI void niels_store(u32* __restrict__ o, const niels& q)
@@ -529,15 +529,16 @@ template <bool ILP = false>
 ZC_DI pt pt_add_cached(const pt& p, const niels& q)
 {
     auto mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
-    const fe A = mul(fp_sub(p.Y, p.X), q.ymx);
+    // carries only where a product needs a normalized side: q's fields are normalized (unpacked
+    // 29-bit limbs), E and F are; Y - X, D = 2 Z Z', G and H stay lazy
+    const fe A = mul(fe_sub_lazy<FP>(p.Y, p.X), q.ymx);
     const fe B = mul(fe_add(p.Y, p.X), q.ypx);
     const fe C = mul(p.T, q.t2d);
     const fe ZZ = mul(p.Z, q.z);
-    fe D = fe_add(ZZ, ZZ);
-    fe_carry(D);
+    const fe D = fe_add(ZZ, ZZ);
     const fe E = fp_sub(B, A);
     const fe F = fp_sub(D, C);
-    const fe G = fe_add(D, C);
+    const fe G = fe_add(D, C);                 // limbs < 1.5 * 2^30, meets F and H (< 2^30)
     const fe H = fe_add(B, A);
     pt r;
     r.X = mul(E, F);
@@ -555,10 +556,11 @@ ZC_DI pt pt_double_fast(const pt& p)
     const fe A = fp_sqr(p.X);
     const fe B = fp_sqr(p.Y);
     const fe ZZ = fp_sqr(p.Z);
-    const fe E = fp_sub(fp_sub(fp_sqr(fe_add(p.X, p.Y)), A), B);     // 2XY
+    // E and G are normalized (one carry pass each); F and H skip it: each meets only E or G in a product
+    const fe E = fe_sub2<FP>(fp_sqr(fe_add(p.X, p.Y)), A, B);         // 2XY
     const fe G = fp_sub(B, A);                                         // D + B with D = a*A = -A
-    const fe F = fp_sub(fp_sub(G, ZZ), ZZ);                            // G - 2Z^2
-    const fe H = fp_sub(fp_neg(A), B);                                 // D - B
+    const fe F = fe_sub2_lazy<FP>(G, ZZ, ZZ);                          // G - 2Z^2
+    const fe H = fe_sub2_lazy<FP>(fe_zero(), A, B);                    // D - B
     pt r;
     r.X = fp_mul(E, F);
     r.Y = fp_mul(G, H);
