@@ -137,7 +137,8 @@ ZC_DI bool limbs52_all_zero(const u64 (&l)[5]) { return (l[0] | l[1] | l[2] | l[
 
 // One lane's share of the batched inversion (Montgomery's trick over `c` consecutive
 // elements starting at `lo`; see k_fe_invert_chunked in zc_kernels.cuh).
-ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, int c)
+// `num` != nullptr turns it into a batched division: out_j = num_j / a_j (Div, field.rs:277-300).
+ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, int c, const u64* num = nullptr)
 {
     const int cnt = (int)((n - lo < (size_t)c) ? (n - lo) : (size_t)c);
     const fe neutral = fe_one_m<FP>();
@@ -162,8 +163,13 @@ ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t
         fe pre;
 #pragma unroll
         for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
-        const fe res = fp_mul(inv, pre);                    // a_j^-1, plain, < 3p
+        fe res = fp_mul(inv, pre);                          // a_j^-1, plain, < 3p
         inv = fp_mul(inv, x);
+        if (num) {
+            u64 ln[5];
+            load5(ln, num + 5 * (lo + j));
+            res = fp_mul(fe_from_limbs52(ln), mont_to<FP>(res));
+        }
         fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(res)));
         if (z) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
         store5(out + 5 * (lo + j), r);

@@ -232,6 +232,11 @@ ZC_KERNEL void k_fe_div(const u64* a, const u64* b, u64* out, uint8_t* ok, size_
     fe_store_canon<FP>(out + 5 * i, fp_mul(x, fp_invert(y)));
     if (ok) ok[i] = nz ? 1 : 0;
 }
+ZC_KERNEL void k_fe_div_chunked(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n, int c)
+{
+    const size_t lo = gid() * (size_t)c;
+    if (lo < n) fe_invert_chunk(b, out, ok, n, lo, c, a);
+}
 ZC_KERNEL void k_fe_half(const u64* a, u64* out, size_t n)                          // field.rs:317-323
 {
     const size_t i = gid();

@@ -615,7 +615,14 @@ int zc_fe_div(zc_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, 
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     Arg args[4] = {in_arg(a, 40), in_arg(b, 40), out_arg(out, 40), out_arg(ok, 1)};
     return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
-        hipLaunchKernelGGL(zc::k_fe_div, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
+        size_t c = cnt / 131072;                           // as zc_fe_invert
+        if (c > 64) c = 64;
+        if (c < 2 || d[2] == d[0] || d[2] == d[1]) {
+            hipLaunchKernelGGL(zc::k_fe_div, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
+        } else {
+            const size_t lanes = (cnt + c - 1) / c;
+            hipLaunchKernelGGL(zc::k_fe_div_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt, (int)c);
+        }
     });
 }
 int zc_fe_half(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_half, a, o, n, 40); }

@@ -158,6 +158,10 @@ extern "C" void emul_ed_to_affine_chunked(const u64* pts, u64* xy, uint8_t* ok, 
 {
     for (size_t lo = 0; lo < n; lo += (size_t)c) ed_to_affine_chunk(pts, xy, ok, n, lo, c);
 }
+extern "C" void emul_fe_div_chunked(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n, int c)
+{
+    for (size_t lo = 0; lo < n; lo += (size_t)c) fe_invert_chunk(b, out, ok, n, lo, c, a);
+}
 extern "C" void emul_ed_scalar_mul_mode(const u64* p, const u64* k, u64* out, size_t n, int mode)
 {
     for (size_t i = 0; i < n; i++) {

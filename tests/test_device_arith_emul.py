@@ -74,6 +74,10 @@ def test_emul_invert_sqrt_ratio(emul, oracle):
         emul.emul_fe_invert_chunked(p(a2), p(out2), p(ok2), C.c_size_t(len(a2)), c)
         want2, wok2 = oracle.fe_invert(a2)
         assert np.array_equal(ok2, wok2) and np.array_equal(out2, want2), c
+        num = V.limbs_array(V.rand_fe(len(a2), V.SEED + 6))
+        emul.emul_fe_div_chunked(p(num), p(a2), p(out2), p(ok2), C.c_size_t(len(a2)), c)
+        wq, wqok = oracle.fe_div(num, a2)
+        assert np.array_equal(ok2, wqok) and np.array_equal(out2, wq), c
     u = V.limbs_array(V.rand_fe(120, V.SEED + 4))
     v = V.limbs_array(list(reversed(V.rand_fe(120, V.SEED + 5))))
     sq = np.empty(len(u), dtype=np.uint8)

@@ -165,6 +165,14 @@ def test_fe_invert_chunked_exact(eng, oracle):
     want, _ = oracle.fe_invert(a[-3000:])
     prod = eng.fe_mul(a, out)
     assert ok.all() and eq(out[-3000:], want) and (prod[:, 0] == 1).all() and not prod[:, 1:].any()
+    # Div (field.rs:277-300) shares the chunked inversion: q * b == a wherever b != 0, exact vs the oracle on a slice
+    num = V.rand_fe_np(n, V.SEED + 30)
+    a[[5, n - 2]] = 0
+    q, qok = eng.fe_div(num, a)
+    wq, wqok = oracle.fe_div(num[:3000], a[:3000])
+    back = eng.fe_mul(q, a)
+    nzd = qok == 1
+    assert eq(q[:3000], wq) and eq(qok[:3000], wqok) and qok.sum() == n - 2 and eq(back[nzd], num[nzd]) and not q[~nzd].any()
 
 
 def test_sqrt_ratio_bulk(eng, oracle):
