@@ -269,8 +269,12 @@ ZC_DI ptm ptm_select(bool c, const ptm& a, const ptm& b)
     r.T = fe_select(c, a.T, b.T);
     return r;
 }
+// ILP: the multiplier with independent column chains, for launches too small to keep more than
+// one wave per SIMD busy (a lone wave cannot hide the serial chain's latency: 15 % faster there).
+template <bool ILP = false>
 ZC_DI ptm ptm_add(const ptm& p, const ptm& q)          // same values as pt_add
 {
+    auto fp_mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
     const fe M = fp_mul(p.Ym, q.Ym);
     const fe P = fp_mul(p.Yp, q.Yp);
     const fe C = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), p.T), q.T);
@@ -349,6 +353,7 @@ ZC_DI void scalar_to_words(u32* __restrict__ sk, int stride, const u64 (&l)[5], 
 // evaluates the HWCD formula once for this lane, either Q + N (pending set bit) or N + N.
 // Under SIMT the lanes of a wave run the loop in lock step, so a wave performs
 // max_lane(bitlen - 1 + popcount) formula evaluations.
+template <bool ILP = false>
 ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int stride, int nbits)
 {
     ptm N = ptm_from_pt(P), Q = ptm_from_pt(pt_identity());
@@ -358,7 +363,7 @@ ZC_DI pt scalar_mul_unified(const pt& P, const u32* __restrict__ sk, int stride,
     bool active = nbits > 0;
     while (active) {
         const ptm lhs = ptm_select(pend, Q, N);
-        const ptm r = ptm_add(lhs, N);
+        const ptm r = ptm_add<ILP>(lhs, N);
         if (pend) {
             Q = r;
             pend = false;

@@ -507,7 +507,8 @@ ZC_KERNEL void k_ed_scalar_mul_bcast(const u64* p, scalar_arg k, u64* out, size_
 
 // k_stride = 5 (one scalar per point).
 // idx != nullptr: batch-wide cost-sorted permutation (k_sm_cost_*); otherwise block-local ranking.
-ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
+template <bool ILP>
+ZC_DI void ed_scalar_mul_body(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
     __shared__ u32 skey[ZC_BLOCK];
@@ -532,8 +533,17 @@ ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64*
     const bool run = idx ? valid : (base + e < n);
     const size_t ii = idx ? own : (run ? base + e : 0);
     const pt P = pt_load(p + 20 * ii);
-    const pt Q = scalar_mul_unified(P, sk + e, ZC_BLOCK, run ? nbits : 0);
+    const pt Q = scalar_mul_unified<ILP>(P, sk + e, ZC_BLOCK, run ? nbits : 0);
     if (run) pt_store(out + 20 * ii, Q);
+}
+ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
+{
+    ed_scalar_mul_body<false>(p, k, k_stride, out, idx, n);
+}
+// the same for launches of at most a few hundred workgroups (one wave per SIMD): independent-chain multiplier
+ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
+{
+    ed_scalar_mul_body<true>(p, k, k_stride, out, idx, n);
 }
 
 // ---- fast (non-strict) scalar multiplication ---------------------------------------------

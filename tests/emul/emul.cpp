@@ -90,6 +90,18 @@ void emul_ed_scalar_mul(const u64* p, const u64* k, u64* out, size_t n)
         pt_store(out + 20 * i, scalar_mul_seq(pt_load(p + 20 * i), l));
     }
 }
+// the small-launch variant: same loop on the independent-chain multiplier
+void emul_ed_scalar_mul_small(const u64* p, const u64* k, u64* out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 l[5];
+        ld5(l, k + 5 * i);
+        u32 w[9];
+        int nbits;
+        scalar_to_words(w, 1, l, nbits);
+        pt_store(out + 20 * i, scalar_mul_unified<true>(pt_load(p + 20 * i), w, 1, nbits));
+    }
+}
 void emul_ed_to_affine(const u64* p, u64* xy, uint8_t* ok, size_t n)
 {
     for (size_t i = 0; i < n; i++) {

@@ -107,6 +107,9 @@ def test_emul_point_ops(emul, oracle):
     K[5] = [0, 0, 0, 0, 1 << 47]
     K[6] = pm.limbs(8)
     emul.emul_ed_scalar_mul(p(P), p(K), p(out), C.c_size_t(n))
+    small = np.empty_like(out)
+    emul.emul_ed_scalar_mul_small(p(P), p(K), p(small), C.c_size_t(n))
+    assert np.array_equal(small, out)
     assert np.array_equal(out, oracle.ed_scalar_mul(P, K))   # strict (X:Y:Z:T) limbs
     Kc = V.rand_scalars_np(n, V.SEED + 14, bits=249)            # canonical scalars (< 2^249 < L)
     Kc[0] = 0
