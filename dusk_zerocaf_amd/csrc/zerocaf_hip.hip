@@ -332,13 +332,18 @@ const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt)
 // variant with independent column chains (2^16 units: 2.09 -> 1.79 ms; from 384 workgroups on the
 // default kernel is faster again).
 constexpr unsigned SMALL_LAUNCH_BLOCKS = 256;
+typedef void (*strict_kernel_t)(const u64*, const u64*, size_t, u64*, const zc::u32*, size_t);
+inline strict_kernel_t strict_kernel_for(size_t cnt)
+{
+    return grid_for(cnt) <= SMALL_LAUNCH_BLOCKS ? zc::k_ed_scalar_mul_small : zc::k_ed_scalar_mul;
+}
 int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
 {
     REQUIRE(p); REQUIRE(k); REQUIRE(out);
     Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
         const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
-        hipLaunchKernelGGL(grid_for(cnt) <= SMALL_LAUNCH_BLOCKS ? zc::k_ed_scalar_mul_small : zc::k_ed_scalar_mul, dim3(grid_for(cnt)),
+        hipLaunchKernelGGL(strict_kernel_for(cnt), dim3(grid_for(cnt)),
                            dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (size_t)5, (u64*)d[2], idx, cnt);
     }, true);
 }
@@ -389,7 +394,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         if (rc) return rc;
         rc = ensure(&D.tmp[1], &D.tmp_bytes[1], ((cnt + 1) / 2) * 160 + 256);
         if (rc) return rc;
-        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, dK, (size_t)5, (u64*)D.tmp[0],
+        hipLaunchKernelGGL(strict_kernel_for(cnt), dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, dK, (size_t)5, (u64*)D.tmp[0],
                            (const zc::u32*)nullptr, cnt);
         *result = fold_all(D, (u64*)D.tmp[0], (u64*)D.tmp[1], cnt);
         HIP_TRY(hipGetLastError());
@@ -476,7 +481,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                            (const zc::u32*)start, (const zc::u32*)end, (const zc::u32*)ib.current(), buckets, nb, c);
         hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)buckets, seg_sum, seg_acc, seg_k, nseg, c);
         // seg_acc <- (lo - 1) * seg_acc ; seg_sum <- seg_sum + seg_acc
-        hipLaunchKernelGGL(zc::k_ed_scalar_mul, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
+        hipLaunchKernelGGL(strict_kernel_for(nseg), dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
                            seg_acc, (const zc::u32*)nullptr, nseg);
         hipLaunchKernelGGL(zc::k_ed_add, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_sum, (const u64*)seg_acc, seg_sum, nseg);
         // fold every window's nseg/W segment sums (power of two per window: pairs never straddle windows)
