@@ -216,6 +216,27 @@ ZC_DI fe mont_mul_ilp(const fe& a, const fe& b)
     return r;
 }
 
+template <class F>
+ZC_DI fe mont_sqr_ilp(const fe& a)
+{
+    for (int i = 0; i < 9; i++) ZC_ASSERT(a.v[i] < (1u << 30));
+    u64 t[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) t[k] = 0;
+    u32 d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        t[2 * i] += (u64)a.v[i] * a.v[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) t[i + j] += (u64)d[i] * a.v[j];
+    }
+    fe r;
+    mont_reduce_cols<F>(r, t);
+    return r;
+}
+
 // r = a / R mod N  (from Montgomery form; reference from_montgomery, field.rs:830-836)
 template <class F>
 ZC_DI fe mont_from(const fe& a)

@@ -226,8 +226,10 @@ ZC_DI pt pt_select(bool c, const pt& a, const pt& b)
 //   H = P - E
 // so a step costs 9 multiplications and X3 = E F, Y3 = G H, Z3 = F G, T3 = E H are the
 // reference's values limb for limb.  Inputs R-class.
+template <bool ILP = false>
 ZC_DI pt pt_add(const pt& p, const pt& q)
 {
+    auto fp_mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
     const fe M = fp_mul(fp_sub(p.Y, p.X), fp_sub(q.Y, q.X));          // operands < 7N: M < 2N
     const fe P = fp_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));          // operands < 6N: P < 2N
     const fe C = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), p.T), q.T);

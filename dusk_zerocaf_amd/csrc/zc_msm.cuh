@@ -157,8 +157,8 @@ ZC_KERNEL void k_msm_segments(const u64* buckets, u64* seg_sum, u64* seg_acc, u6
     // already sum_d d * B_d and its scalar is 0
     const int jmin = (lo == 0) ? 1 : 0;
     for (int j = MSM_SEG - 1; j >= jmin; j--) {
-        acc = pt_add(acc, pt_load(buckets + 20 * (first + j)));
-        sum = pt_add(sum, acc);
+        acc = pt_add<true>(acc, pt_load(buckets + 20 * (first + j)));
+        sum = pt_add<true>(sum, acc);
     }
     pt_store(seg_sum + 20 * s, sum);
     pt_store(seg_acc + 20 * s, acc);
@@ -188,13 +188,14 @@ ZC_DI fe fe_by_role(int role, const fe& a, const fe& b, const fe& c, const fe& d
 }
 ZC_DI pt pt_double_quad(const pt& p, int role)
 {
-    const fe sq = fp_sqr(fe_by_role(role, p.X, p.Y, p.Z, fe_add(p.X, p.Y)));
+    // one wave, nothing to overlap with: the independent-chain multiplier has the shorter latency
+    const fe sq = mont_sqr_ilp<FP>(fe_by_role(role, p.X, p.Y, p.Z, fe_add(p.X, p.Y)));
     const fe A = quad_bcast<0>(sq), B = quad_bcast<1>(sq), ZZ = quad_bcast<2>(sq), S = quad_bcast<3>(sq);
     const fe E = fp_sub(fp_sub(S, A), B);
     const fe G = fp_sub(B, A);
     const fe F = fp_sub(fp_sub(G, ZZ), ZZ);
     const fe H = fp_sub(fp_neg(A), B);
-    const fe m = fp_mul(fe_by_role(role, E, G, F, E), fe_by_role(role, F, H, G, H));
+    const fe m = mont_mul_ilp<FP>(fe_by_role(role, E, G, F, E), fe_by_role(role, F, H, G, H));
     pt r;
     r.X = quad_bcast<0>(m);
     r.Y = quad_bcast<1>(m);
@@ -209,7 +210,7 @@ ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c)
     pt Q = pt_load(windows + 20 * (size_t)(W - 1));
     for (int w = W - 2; w >= 0; w--) {
         for (int i = 0; i < c; i++) Q = pt_double_quad(Q, role);
-        Q = pt_add(Q, pt_load(windows + 20 * (size_t)w));
+        Q = pt_add<true>(Q, pt_load(windows + 20 * (size_t)w));
     }
     if (threadIdx.x == 0) pt_store(out, Q);
 }
