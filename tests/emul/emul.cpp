@@ -62,6 +62,17 @@ void emul_fe_square(const u64* a, u64* out, size_t n, int modl)
         else store_plain<ModP>(out + 5 * i, mont_mul<ModP>(mont_sqr<ModP>(fe_from_limbs52(x)), fe_const<ModP>(ModP::RR)));
     }
 }
+// the independent-chain multiplier pair used by small launches and the MSM bucket sums
+void emul_fe_mul_square_ilp(const u64* a, const u64* b, u64* prod, u64* sq, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 x[5], y[5];
+        ld5(x, a + 5 * i);
+        ld5(y, b + 5 * i);
+        store_plain<ModP>(prod + 5 * i, mont_mul_ilp<ModP>(mont_mul_ilp<ModP>(fe_from_limbs52(x), fe_const<ModP>(ModP::RR)), fe_from_limbs52(y)));
+        store_plain<ModP>(sq + 5 * i, mont_mul_ilp<ModP>(mont_sqr_ilp<ModP>(fe_from_limbs52(x)), fe_const<ModP>(ModP::RR)));
+    }
+}
 void emul_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
 {
     for (size_t i = 0; i < n; i++) {

@@ -51,6 +51,11 @@ def test_emul_mul_square(emul, oracle):
         assert np.array_equal(out, orc_mul(a, b))
         emul.emul_fe_square(p(a), p(out), C.c_size_t(len(a)), modl)
         assert np.array_equal(out, orc_sq(a))
+    a = V.limbs_array(V.rand_fe(2000, V.SEED + 1))
+    b = V.limbs_array(list(reversed(V.rand_fe(2000, V.SEED + 2))))
+    prod, sq = np.empty_like(a), np.empty_like(a)
+    emul.emul_fe_mul_square_ilp(p(a), p(b), p(prod), p(sq), C.c_size_t(len(a)))      # independent-chain pair
+    assert np.array_equal(prod, oracle.fe_mul(a, b)) and np.array_equal(sq, oracle.fe_square(a))
     # non-canonical operands with limbs < 2^52 are value-correct too
     rng = np.random.default_rng(7)
     a = rng.integers(0, 1 << 52, size=(500, 5), dtype=np.uint64)
