@@ -59,7 +59,7 @@ typedef enum zc_status {
 #define ZC_SCALAR_MUL_BINARY_NAF 2u  /* binary_naf_mul, src/edwards.rs:136-153 (canonical k < L) */
 /* NOT limb-exact: fixed signed windows + dedicated doubling.  The result is the same group
  * element as Mul<Scalar> (== per src/edwards.rs:360-370, identical compress()/Ristretto bytes);
- * its (X:Y:Z:T) limbs differ by a projective factor.  ~1.6x the strict throughput.          */
+ * its (X:Y:Z:T) limbs differ by a projective factor.  ~1.5x the strict throughput.          */
 #define ZC_SCALAR_MUL_FAST 16u
 
 /* ---- context -------------------------------------------------------------- */
