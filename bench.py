@@ -39,7 +39,7 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_inputs(eng, torch, n, seed, workload):
+def make_inputs(eng, torch, n, seed, workload, scalar_bits=252):
     """Synthetic, seeded, generated on the GPU box: P_i = r_i * B (valid subgroup points in
     non-trivial extended coordinates, produced by the engine's fixed-base kernel) and S252 scalars."""
     rng = np.random.default_rng(seed)
@@ -56,7 +56,7 @@ def make_inputs(eng, torch, n, seed, workload):
         return {"a": to_dev(a), "b": to_dev(b), "host": (a, b)}
     P = eng.ed_mul_base(to_dev(scalars(249)))
     torch.cuda.synchronize()
-    K = scalars(252)
+    K = scalars(scalar_bits)
     d = {"P": P, "K": to_dev(K), "host_K": K}
     if workload == "ristretto":
         d["enc"] = eng.ris_compress(P)
@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--units", "--n", dest="n", type=int, default=1 << 20, help="units per GPU per step")
     ap.add_argument("--workload", default="scalar_mul", choices=["scalar_mul", "fe_mul", "ristretto", "msm"])
+    ap.add_argument("--scalar-bits", type=int, default=252, choices=[249, 252],
+                    help="252 = uniform raw 252-bit scalars (BASELINE wording, headline); 249 = the reference's Scalar::random domain")
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"],
                     help="scalar_mul only: strict = reference formula sequence (bit-exact X:Y:Z:T limbs, the "
                          "headline); fast = windowed non-strict mode (same group element, labelled extra)")
@@ -152,7 +154,7 @@ def main():
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     n = args.n
-    data = make_inputs(eng, torch, n, 0x5EED0003 + rank, args.workload)
+    data = make_inputs(eng, torch, n, 0x5EED0003 + rank, args.workload, args.scalar_bits)
 
     if args.workload == "scalar_mul":
         out = torch.empty_like(data["P"])
@@ -225,7 +227,7 @@ def main():
             pass
     ub = os.path.join(ROOT, "profiles", "r01_ubench.json")
     mix = os.path.join(ROOT, "profiles", "r01_isa_mix.json")
-    if args.workload == "scalar_mul" and args.mode == "strict" and os.path.exists(ub) and os.path.exists(mix):
+    if args.workload == "scalar_mul" and args.mode == "strict" and args.scalar_bits == 252 and os.path.exists(ub) and os.path.exists(mix):
         try:
             u, m = json.load(open(ub)), json.load(open(mix))
             mad_peak = float(u["v_mad_u64_u32_lane_ops_per_s"])          # lane-ops/s, all CUs, tools/ubench
@@ -290,7 +292,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64 (nine 29-bit limbs in u32 registers, 64-bit multiply-accumulate columns)", "data": "synthetic",
-        "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random 252-bit scalars (BASELINE configs[2])",
+        "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random %d-bit scalars (BASELINE configs[2])" % args.scalar_bits,
                                 "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
                                 "ristretto": "Ristretto decompress->scalar-mul->compress (BASELINE configs[3] shape)",
                                 "msm": "Pippenger MSM, 249-bit scalars, one shard per GPU (BASELINE configs[4] shape)"}[args.workload],
