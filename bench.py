@@ -286,9 +286,10 @@ def main():
                    else "252-bit Edwards variable-base scalar-muls/sec (batched, FAST non-strict mode)")
         if args.workload == "scalar_mul" else
         ("MSM point-scalar pairs/sec (bucket method per GPU, all-gather + ordered fold across GPUs)" if args.workload == "msm"
-         else args.workload + " units/sec"),
+         else {"ristretto": "Ristretto decompress -> scalar-mul -> compress round trips/sec (fused, bit-exact encodings)",
+               "fe_mul": "FieldElement multiplications/sec (batched, bit-exact canonical limbs)"}[args.workload]),
         "value": round(value, 1),
-        "unit": {"fe_mul": "field-muls/s", "msm": "pairs/s"}.get(args.workload, "scalar-muls/s"),
+        "unit": {"fe_mul": "field-muls/s", "msm": "pairs/s", "ristretto": "round-trips/s"}.get(args.workload, "scalar-muls/s"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
