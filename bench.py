@@ -123,7 +123,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--units", "--n", dest="n", type=int, default=1 << 20, help="units per GPU per step")
     ap.add_argument("--workload", default="scalar_mul", choices=["scalar_mul", "fe_mul", "ristretto", "msm"])
     ap.add_argument("--scalar-bits", type=int, default=252, choices=[249, 252],

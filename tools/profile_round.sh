@@ -18,7 +18,7 @@ pmc() { local name=$1 ctrs=$2; shift 2; timeout 600 rocprofv3 --pmc $ctrs --outp
 kt scalar_mul --steps 5 --warmup 1
 kt ristretto --workload ristretto --steps 5 --warmup 1
 kt msm --workload msm --steps 5 --warmup 1
-kt fe_mul --workload fe_mul --units 16777216 --steps 10 --warmup 2
+kt fe_mul --workload fe_mul --units 16777216 --steps 20 --warmup 30
 pmc fetch FETCH_SIZE --steps 2 --warmup 1
 pmc write WRITE_SIZE --steps 2 --warmup 1
 pmc sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1
@@ -31,7 +31,7 @@ python bench.py --mode fast --cpu-sample 0 > "$OUT/bench_scalar_mul_fast.json" 2
 python bench.py --workload ristretto --cpu-sample 0 > "$OUT/bench_ristretto.json" 2>/dev/null
 python bench.py --workload ristretto --units 4194304 --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/bench_ristretto_2p22.json" 2>/dev/null
 python bench.py --workload fe_mul --cpu-sample 0 > "$OUT/bench_fe_mul_2p20.json" 2>/dev/null
-python bench.py --workload fe_mul --units 16777216 --steps 10 --warmup 2 --cpu-sample 0 > "$OUT/bench_fe_mul_2p24.json" 2>/dev/null
+python bench.py --workload fe_mul --units 16777216 --steps 20 --warmup 30 --cpu-sample 0 > "$OUT/bench_fe_mul_2p24.json" 2>/dev/null
 python bench.py --workload msm --cpu-sample 0 > "$OUT/bench_msm.json" 2>/dev/null
 python bench.py --workload msm --units 2097152 --cpu-sample 0 > "$OUT/bench_msm_2p21.json" 2>/dev/null
 python bench.py --workload msm --units 16777216 --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/bench_msm_2p24.json" 2>/dev/null

@@ -19,11 +19,13 @@ KT = [("scalar_mul", "`rocprofv3 --kernel-trace --stats -- python bench.py --ste
       ("ristretto", "`... --workload ristretto` (fused decompress -> scalar-mul -> compress on the windowed core, 2^20; "
                     "inputs come from k_ed_mul_base + k_ris_compress)"),
       ("msm", "`... --workload msm` (bucket method, 2^20 pairs per launch)"),
-      ("fe_mul", "`... --workload fe_mul --units 16777216 --steps 10 --warmup 2` (2^24 elements, 2.0 GB per launch)")]
+      ("fe_mul", "`... --workload fe_mul --units 16777216 --steps 20 --warmup 30` (2^24 elements, 2.0 GB per launch; the long warm-up "
+       "steps over the board's power transient: from idle the launches run 0.36 ms, rise to 0.50 ms around the tenth and "
+       "settle at 0.39-0.42 ms)")]
 
 
 DOMINANT = {"scalar_mul": "k_ed_scalar_mul", "ristretto": "k_ris_roundtrip_mul_fast", "fe_mul": "k_fe_mul"}
-WARMUP = {"scalar_mul": 1, "ristretto": 1, "fe_mul": 2}
+WARMUP = {"scalar_mul": 1, "ristretto": 1, "fe_mul": 30}
 
 
 def kernel_table(path):
@@ -71,7 +73,7 @@ def main():
             durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace))
                     if r["Kernel_Name"].startswith(DOMINANT[name])]
             timed = durs[WARMUP[name]:]
-            md += ["%s per dispatch, in order (ms): %s.  Warm-up launches first: %d (clocks still ramping); the "
+            md += ["%s per dispatch, in order (ms): %s.  Warm-up launches first: %d; the "
                    "%d timed launches average %.3f ms, which is what bench.py reports as `kernel_avg_ms`." % (
                        DOMINANT[name], ", ".join("%.2f" % d for d in durs), WARMUP[name], len(timed), sum(timed) / len(timed)), ""]
         if name == "scalar_mul":
