@@ -559,7 +559,8 @@ ZC_DI niels niels_load(const u32* __restrict__ c)
 // p + q, q cached: 8 multiplications (unified and complete for a = -1, d non-square).
 // ILP selects the multiplier with independent column chains (mont_mul_ilp) for memory-latency
 // bound callers.
-template <bool ILP = false>
+// AFFINE: q.z == 1 (a table normalised once), so Z Z' is just Z: 7 multiplications.
+template <bool ILP = false, bool AFFINE = false>
 ZC_DI pt pt_add_cached(const pt& p, const niels& q)
 {
     auto mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
@@ -568,7 +569,7 @@ ZC_DI pt pt_add_cached(const pt& p, const niels& q)
     const fe A = mul(fe_sub_lazy<FP>(p.Y, p.X), q.ymx);
     const fe B = mul(fe_add(p.Y, p.X), q.ypx);
     const fe C = mul(p.T, q.t2d);
-    const fe ZZ = mul(p.Z, q.z);
+    const fe ZZ = AFFINE ? p.Z : mul(p.Z, q.z);
     const fe D = fe_add(ZZ, ZZ);
     const fe E = fp_sub(B, A);
     const fe F = fp_sub(D, C);

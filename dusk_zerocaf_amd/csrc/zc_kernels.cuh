@@ -598,7 +598,7 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
 // The reference's only fixed-base routine, window_naf_mul (edwards.rs:155-171), mis-indexes its
 // odd-multiples table and its test is commented out; the key-generation half of its ECDH bench
 // therefore uses the variable-base algorithms on BASEPOINT.  This is the correct fixed-base
-// counterpart: a comb table T[w][j] = (j+1) * 16^w * B (66 windows x 8 cached points, 66 KB,
+// counterpart: a comb table T[w][j] = (j+1) * 16^w * B (66 windows x 8 cached affine points, 66 KB,
 // L2-resident) and k*B = sum_w sign(d_w) * T[w][|d_w| - 1] over the signed radix-16 digits --
 // 66 cached additions, no doublings.  Equal to `&BASEPOINT * &k` as a group element; the fused
 // variant emits Ristretto encodings, which are bit-identical to the reference's.
@@ -620,7 +620,14 @@ ZC_KERNEL void k_base_table_build(u32* table)
         P = pt_select(a < j, s, P);                       // P = (j+1) * B
     }
     for (int w = 0; w < ZC_BASE_WINDOWS; w++) {
-        niels_store(table + 32 * (w * 8 + j), niels_from_pt(P));
+        // entries are normalised to Z = 1 once, here, so every later addition against them is mixed
+        const fe zi = fp_invert(P.Z);
+        pt A;
+        A.X = fp_mul(P.X, zi);
+        A.Y = fp_mul(P.Y, zi);
+        A.Z = fe_one_m<FP>();
+        A.T = fp_mul(A.X, A.Y);
+        niels_store(table + 32 * (w * 8 + j), niels_from_pt(A));
         P = pt_add(P, P);
         P = pt_add(P, P);
         P = pt_add(P, P);
@@ -635,7 +642,7 @@ ZC_DI pt base_mul(const u32* __restrict__ table, const int8_t* __restrict__ dig,
         const int mag = d < 0 ? -d : d;
         niels c = niels_identity();
         if (mag != 0) c = niels_load(table + 32 * (w * 8 + mag - 1));
-        Q = pt_add_cached(Q, niels_cond_neg(d < 0, c));
+        Q = pt_add_cached<false, true>(Q, niels_cond_neg(d < 0, c));     // table entries and the identity have z = 1
     }
     return Q;
 }
