@@ -11,6 +11,8 @@
 //   CompressedEdwardsY::decompress :313-326 (std::optional = Option)
 //   RistrettoPoint / CompressedRistretto  src/ristretto.rs (:96-154, :166-176, :224-425)
 //   mul_by_cofactor / mul_by_pow_2  src/edwards.rs:174-191
+//   AffinePoint::from :1071-1092, ProjectivePoint add/double/into :809-942/:402-417, is_valid,
+//   Elligator / from_uniform_bytes  src/ristretto.rs:430-507; msm / fixed-base batches (not in the reference)
 // Single-element operators are batches of one (convenience / tests); use the *_batch
 // functions for throughput.  All arithmetic runs on the GPU; there is no CPU path.
 #pragma once
@@ -37,6 +39,12 @@ public:
     {
         if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + zc_last_error());
     }
+    static int device_count() { return zc_device_count(); }
+    static std::string version() { return zc_version(); }
+    // launch on the caller's hipStream_t (device buffers: calls become asynchronous on it) / back to the own stream
+    static void set_stream(void* hip_stream) { check(zc_ctx_set_stream(ctx(), hip_stream, 1), "zc_ctx_set_stream"); }
+    static void use_own_stream() { check(zc_ctx_set_stream(ctx(), nullptr, 0), "zc_ctx_set_stream"); }
+    static void synchronize() { check(zc_ctx_synchronize(ctx()), "zc_ctx_synchronize"); }
 
 private:
     Backend() { check(zc_ctx_create(nullptr, 0, &ctx_), "zc_ctx_create"); }
@@ -70,8 +78,11 @@ struct FieldElement {
     }
     FieldElement operator/(const FieldElement& b) const
     {
-        if (b == zero()) throw std::domain_error("Cannot divide by zero.");   // field.rs:285
-        return *this * b.inverse();
+        FieldElement r;
+        uint8_t ok = 0;
+        Backend::check(zc_fe_div(Backend::ctx(), l.data(), b.l.data(), r.l.data(), &ok, 1), "zc_fe_div");
+        if (!ok) throw std::domain_error("Cannot divide by zero.");           // field.rs:285
+        return r;
     }
     FieldElement half() const { FieldElement r; Backend::check(zc_fe_half(Backend::ctx(), l.data(), r.l.data(), 1), "zc_fe_half"); return r; }   // Half, field.rs:317-323
     FieldElement pow(const FieldElement& e) const                                       // Pow, field.rs:325-355
@@ -244,7 +255,72 @@ struct EdwardsPoint {
         Backend::check(zc_ed_eq(Backend::ctx(), a, b, &e, 1), "zc_ed_eq");
         return e != 0;
     }
+    bool is_valid() const                                                   // ValidityCheck, edwards.rs:393-400
+    {
+        uint64_t a[20];
+        uint8_t v = 0;
+        flat(a);
+        Backend::check(zc_ed_is_valid(Backend::ctx(), a, &v, 1), "zc_ed_is_valid");
+        return v != 0;
+    }
     inline CompressedEdwardsY compress() const;
+};
+
+// AffinePoint::from(EdwardsPoint), edwards.rs:1071-1092 (throws where the inverse of Z = 0 panics)
+struct AffinePoint {
+    FieldElement X, Y;
+    static AffinePoint from(const EdwardsPoint& p)
+    {
+        uint64_t a[20], xy[10];
+        uint8_t ok = 0;
+        p.flat(a);
+        Backend::check(zc_ed_to_affine(Backend::ctx(), a, xy, &ok, 1), "zc_ed_to_affine");
+        if (!ok) throw std::domain_error("inverse of zero");
+        AffinePoint r;
+        std::memcpy(r.X.l.data(), xy, 40);
+        std::memcpy(r.Y.l.data(), xy + 5, 40);
+        return r;
+    }
+};
+
+// ProjectivePoint (edwards.rs:666-998): add :809-865, double :905-942, into EdwardsPoint :402-417
+struct ProjectivePoint {
+    FieldElement X, Y, Z;
+    void flat(uint64_t* o) const
+    {
+        std::memcpy(o, X.l.data(), 40);
+        std::memcpy(o + 5, Y.l.data(), 40);
+        std::memcpy(o + 10, Z.l.data(), 40);
+    }
+    static ProjectivePoint unflat(const uint64_t* p)
+    {
+        ProjectivePoint r;
+        std::memcpy(r.X.l.data(), p, 40);
+        std::memcpy(r.Y.l.data(), p + 5, 40);
+        std::memcpy(r.Z.l.data(), p + 10, 40);
+        return r;
+    }
+    ProjectivePoint operator+(const ProjectivePoint& q) const
+    {
+        uint64_t a[15], b[15], o[15];
+        flat(a); q.flat(b);
+        Backend::check(zc_proj_add(Backend::ctx(), a, b, o, 1), "zc_proj_add");
+        return unflat(o);
+    }
+    ProjectivePoint double_() const
+    {
+        uint64_t a[15], o[15];
+        flat(a);
+        Backend::check(zc_proj_double(Backend::ctx(), a, o, 1), "zc_proj_double");
+        return unflat(o);
+    }
+    EdwardsPoint to_extended() const
+    {
+        uint64_t a[15], o[20];
+        flat(a);
+        Backend::check(zc_proj_to_extended(Backend::ctx(), a, o, 1), "zc_proj_to_extended");
+        return EdwardsPoint::unflat(o);
+    }
 };
 
 struct CompressedEdwardsY {
@@ -301,6 +377,26 @@ struct RistrettoPoint {
         p.flat(a); q.p.flat(b);
         Backend::check(zc_ris_eq(Backend::ctx(), a, b, &e, 1), "zc_ris_eq");
         return e != 0;
+    }
+    bool is_valid() const                                                   // ristretto.rs:205-222
+    {
+        uint64_t a[20];
+        uint8_t v = 0;
+        p.flat(a);
+        Backend::check(zc_ris_is_valid(Backend::ctx(), a, &v, 1), "zc_ris_is_valid");
+        return v != 0;
+    }
+    static RistrettoPoint elligator_ristretto_flavor(const FieldElement& r0)   // ristretto.rs:430-471
+    {
+        uint64_t o[20];
+        Backend::check(zc_ris_elligator(Backend::ctx(), r0.l.data(), o, 1), "zc_ris_elligator");
+        return {EdwardsPoint::unflat(o)};
+    }
+    static RistrettoPoint from_uniform_bytes(const std::array<uint8_t, 64>& b)   // ristretto.rs:493-507
+    {
+        uint64_t o[20];
+        Backend::check(zc_ris_from_uniform_bytes(Backend::ctx(), b.data(), o, 1), "zc_ris_from_uniform_bytes");
+        return {EdwardsPoint::unflat(o)};
     }
     inline CompressedRistretto compress() const;
 };
@@ -373,6 +469,41 @@ inline std::vector<std::optional<CompressedRistretto>> ristretto_roundtrip_mul_b
             r[i] = c;
         }
     return r;
+}
+
+// sum_i k_i * P_i (bucket method on the GPU); equal to the fold of operator* and operator+ under ==
+inline EdwardsPoint msm(const std::vector<EdwardsPoint>& ps, const std::vector<Scalar>& ks)
+{
+    if (ps.size() != ks.size()) throw std::invalid_argument("msm: size mismatch");
+    std::vector<uint64_t> p(ps.size() * 20), k(ks.size() * 5);
+    for (size_t i = 0; i < ps.size(); i++) {
+        ps[i].flat(&p[20 * i]);
+        std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    }
+    uint64_t o[20];
+    Backend::check(zc_msm(Backend::ctx(), p.data(), k.data(), ps.size(), o), "zc_msm");
+    return EdwardsPoint::unflat(o);
+}
+// k * BASEPOINT from the fixed-base table: equal to `BASEPOINT * k` under == (not limb-identical)
+inline std::vector<EdwardsPoint> mul_base_batch(const std::vector<Scalar>& ks)
+{
+    std::vector<uint64_t> k(ks.size() * 5), o(ks.size() * 20);
+    for (size_t i = 0; i < ks.size(); i++) std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    Backend::check(zc_ed_mul_base(Backend::ctx(), k.data(), o.data(), ks.size()), "zc_ed_mul_base");
+    std::vector<EdwardsPoint> out(ks.size());
+    for (size_t i = 0; i < ks.size(); i++) out[i] = EdwardsPoint::unflat(&o[20 * i]);
+    return out;
+}
+// key generation: (RISTRETTO_BASEPOINT * k).compress(), identical bytes
+inline std::vector<CompressedRistretto> ristretto_keygen_batch(const std::vector<Scalar>& ks)
+{
+    std::vector<uint64_t> k(ks.size() * 5);
+    std::vector<uint8_t> o(ks.size() * 32);
+    for (size_t i = 0; i < ks.size(); i++) std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    Backend::check(zc_ris_mul_base_compress(Backend::ctx(), k.data(), o.data(), ks.size()), "zc_ris_mul_base_compress");
+    std::vector<CompressedRistretto> out(ks.size());
+    for (size_t i = 0; i < ks.size(); i++) std::memcpy(out[i].bytes.data(), &o[32 * i], 32);
+    return out;
 }
 
 namespace constants {

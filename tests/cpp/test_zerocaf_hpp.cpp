@@ -121,6 +121,36 @@ int main()
         const EdwardsPoint s = ps[i] * ks[i];
         CHECK(outs[i].X.l == s.X.l && outs[i].Y.l == s.Y.l && outs[i].Z.l == s.Z.l && outs[i].T.l == s.T.l);
     }
+    // ---- the rest of the ABI through the mirror: affine / projective / validity / hash-to-group /
+    //      fixed base / MSM, checked against the operators above
+    CHECK(Backend::device_count() >= 1 && !Backend::version().empty());
+    const AffinePoint a4 = AffinePoint::from(P4);                                                           // edwards.rs:1071-1092
+    CHECK(a4.X * P4.Z == P4.X && a4.Y * P4.Z == P4.Y);
+    threw = false;
+    try { (void)AffinePoint::from(EdwardsPoint{P4.X, P4.Y, FieldElement::zero(), P4.T}); } catch (const std::domain_error&) { threw = true; }
+    CHECK(threw);
+    const ProjectivePoint pp1{P1.X, P1.Y, P1.Z}, pp2{P2.X, P2.Y, P2.Z};
+    CHECK((pp1 + pp2).to_extended() == P4 && pp1.double_().to_extended() == P1.double_());                  // edwards.rs:809-942
+    CHECK(P1.is_valid() && P4.is_valid() && !EdwardsPoint{P1.X, P1.Y + FieldElement::one(), P1.Z, P1.T}.is_valid());
+    CHECK(Bp.is_valid() && (Bp * Y).is_valid());
+    std::array<uint8_t, 64> ub{};
+    for (int i = 0; i < 64; i++) ub[i] = (uint8_t)(7 * i + 1);
+    const RistrettoPoint hp = RistrettoPoint::from_uniform_bytes(ub);                                       // ristretto.rs:493-507
+    CHECK(hp.p.is_valid());                                          // on the curve (order divides 8L, so the order-L check may fail)
+    CHECK(hp.compress().decompress().has_value() && *hp.compress().decompress() == hp);
+    CHECK(RistrettoPoint::elligator_ristretto_flavor(FieldElement(5)).p.is_valid());
+    EdwardsPoint fold = EdwardsPoint::identity();
+    for (size_t i = 0; i < ps.size(); i++) fold = fold + outs[i];
+    CHECK(msm(ps, ks) == fold);
+    const auto kb = mul_base_batch(ks);
+    const auto keys = ristretto_keygen_batch(ks);
+    for (size_t i = 0; i < ks.size(); i++) {
+        CHECK(kb[i] == constants::BASEPOINT() * ks[i]);
+        CHECK(keys[i] == (Bp * ks[i]).compress());
+    }
+    const auto rt = ristretto_roundtrip_mul_batch({Bp.compress(), hp.compress()}, {Y, X});
+    CHECK(rt[0].has_value() && *rt[0] == (Bp * Y).compress() && rt[1].has_value() && *rt[1] == (hp * X).compress());
+    Backend::synchronize();
     if (failures) { std::printf("%d FAILURES\n", failures); return 1; }
     std::printf("zerocaf.hpp: all reference-style checks passed\n");
     return 0;

@@ -72,3 +72,10 @@ def test_rust_shim_binds_the_whole_abi():
     shim = open(os.path.join(os.path.dirname(gen.OUT), "lib.rs")).read()
     used = set(re.findall(r"ffi::(zc_[a-z0-9_]+)", shim))
     assert used == declared, sorted(declared - used)
+
+
+def test_cpp_mirror_covers_the_whole_abi():
+    """dusk_zerocaf_amd/include/zerocaf.hpp (the C++ host-side mirror) reaches every entry point."""
+    hpp = open(os.path.join(ROOT, "dusk_zerocaf_amd", "include", "zerocaf.hpp")).read()
+    missing = [s for s in declared_symbols() if s + "(" not in hpp]
+    assert not missing, missing

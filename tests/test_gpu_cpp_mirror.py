@@ -14,7 +14,9 @@ def test_cpp_mirror_reference_style_checks():
     src = os.path.join(ROOT, "tests", "cpp", "test_zerocaf_hpp.cpp")
     exe = os.path.join(ROOT, "tests", "cpp", "test_zerocaf_hpp")
     libdir = os.path.join(ROOT, "dusk_zerocaf_amd")
-    if shutil.which("g++") and (not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src)):
+    hpp = os.path.join(ROOT, "dusk_zerocaf_amd", "include", "zerocaf.hpp")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hpp))
+    if shutil.which("g++") and (not os.path.exists(exe) or os.path.getmtime(exe) < newest):
         subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe, "-L", libdir, "-lzerocaf_hip",
                                "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
