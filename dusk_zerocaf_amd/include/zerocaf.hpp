@@ -62,6 +62,13 @@ struct FieldElement {
     static FieldElement zero() { return FieldElement(); }
     static FieldElement one() { return FieldElement(std::array<uint64_t, 5>{1, 0, 0, 0, 0}); }
     static FieldElement minus_one() { return FieldElement(std::array<uint64_t, 5>{671914833335276ull, 3916664325105025ull, 1367801ull, 0, 17592186044416ull}); }
+    static FieldElement two_pow_k(uint64_t k)                               // field.rs:640-666 (host-side constructor, as in the reference)
+    {
+        if (k >= 253) throw std::domain_error("Exponent can't be greater than 260");
+        FieldElement r;
+        r.l[k / 52] = 1ull << (k % 52);
+        return r;
+    }
 
     FieldElement operator+(const FieldElement& b) const { FieldElement r; Backend::check(zc_fe_add(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_fe_add"); return r; }
     FieldElement operator-(const FieldElement& b) const { FieldElement r; Backend::check(zc_fe_sub(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_fe_sub"); return r; }

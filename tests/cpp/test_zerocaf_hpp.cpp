@@ -49,6 +49,7 @@ int main()
           FieldElement(17).mod_sqrt(false)->l == L5{933733106825591ull, 3470287880816342ull, 2891894702196915ull, 3836949834964192ull, 14650685232542ull}); // mod_sqrt_tonelli_shanks
     CHECK(!A.mod_sqrt(false).has_value() && !A.mod_sqrt(true).has_value());                                 // non_QRmod_sqrt
     CHECK(A.is_even() && !B.is_even());                                                                     // evenness
+    CHECK(FieldElement::two_pow_k(156).l == L5{0, 0, 0, 1, 0} && (FieldElement::two_pow_k(157)).l == A.l);  // two_pow_k
     const std::array<uint8_t, 32> m1b = {236, 211, 245, 92, 26, 99, 18, 88, 214, 156, 247, 162, 222, 249, 222, 20, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16};
     CHECK(FieldElement::from_bytes(m1b).l == FieldElement::minus_one().l && FieldElement::minus_one().to_bytes() == m1b);
 
