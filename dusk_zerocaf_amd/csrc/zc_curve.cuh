@@ -585,9 +585,11 @@ ZC_DI pt pt_add_cached(const pt& p, const niels& q)
 
 // Dedicated doubling, a = -1 (HWCD'08 sec. 3.3 "dbl-2008-hwcd"): 4S + 3M, + 1M when T is wanted.
 // Used only where results are compared as group elements or leave as canonical encodings.
-template <bool WITH_T>
+template <bool WITH_T, bool ILP = false>
 ZC_DI pt pt_double_fast(const pt& p)
 {
+    auto fp_mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
+    auto fp_sqr = [](const fe& x) { return ILP ? mont_sqr_ilp<FP>(x) : mont_sqr<FP>(x); };
     const fe A = fp_sqr(p.X);
     const fe B = fp_sqr(p.Y);
     const fe ZZ = fp_sqr(p.Z);
@@ -629,6 +631,25 @@ ZC_DI int scalar_digits16(int8_t* __restrict__ dig, int stride, const u64 (&l)[5
     return top;
 }
 
+template <bool ILP>
+ZC_DI pt fast_window_loop(const u32* __restrict__ table, const int8_t* __restrict__ dig, int stride, int top)
+{
+    pt Q = pt_identity();
+    for (int i = top; i >= 0; i--) {
+        if (i != top) {
+            Q = pt_double_fast<false, ILP>(Q);
+            Q = pt_double_fast<false, ILP>(Q);
+            Q = pt_double_fast<false, ILP>(Q);
+            Q = pt_double_fast<true, ILP>(Q);
+        }
+        const int d = dig[i * stride];
+        const int mag = d < 0 ? -d : d;
+        niels c = niels_identity();
+        if (mag != 0) c = niels_load(table + 32 * (mag - 1));
+        Q = pt_add_cached<ILP>(Q, niels_cond_neg(d < 0, c));
+    }
+    return Q;
+}
 // k * P with fixed signed 4-bit windows over a per-lane table {1P..8P} of cached points in
 // global scratch (8 x 128 bytes per point, one cache line per entry).  Uniform control flow:
 // every lane of a wave runs the same schedule from window `top` (wave-uniform) down to 0.
@@ -655,21 +676,8 @@ ZC_DI pt scalar_mul_fast(const pt& P, u32* __restrict__ table, const int8_t* __r
         const pt p8 = pt_double_fast<true>(p4);
         niels_store(table + 224, niels_from_pt(p8));
     }
-    pt Q = pt_identity();
-    for (int i = top; i >= 0; i--) {
-        if (i != top) {
-            Q = pt_double_fast<false>(Q);
-            Q = pt_double_fast<false>(Q);
-            Q = pt_double_fast<false>(Q);
-            Q = pt_double_fast<true>(Q);
-        }
-        const int d = dig[i * stride];
-        const int mag = d < 0 ? -d : d;
-        niels c = niels_identity();
-        if (mag != 0) c = niels_load(table + 32 * (mag - 1));
-        Q = pt_add_cached(Q, niels_cond_neg(d < 0, c));
-    }
-    return Q;
+    // small launches (one wave per SIMD) take the independent-chain multiplier, like the strict kernel
+    return zc_small_launch() ? fast_window_loop<true>(table, dig, stride, top) : fast_window_loop<false>(table, dig, stride, top);
 }
 
 // ---------------------------------------------------------------- byte codecs
