@@ -17,6 +17,7 @@
 //   7. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling
 #pragma once
 #include "zc_kernels.cuh"
+#include "zc_quad.cuh"
 
 namespace zc {
 
@@ -174,18 +175,6 @@ ZC_KERNEL void k_msm_segments(const u64* buckets, u64* seg_sum, u64* seg_acc, u6
 // (dbl-2008-hwcd, a = -1), and DPP quad broadcasts hand the four results round; a doubling then
 // costs one squaring plus one multiplication of latency instead of eight.  Result compared as a
 // group element (zc_msm contract), so the dedicated doubling is admissible here.
-template <int J>
-ZC_DI fe quad_bcast(const fe& x)
-{
-    fe r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.v[i], J * 0x55, 0xF, 0xF, false);
-    return r;
-}
-ZC_DI fe fe_by_role(int role, const fe& a, const fe& b, const fe& c, const fe& d)
-{
-    return fe_select(role < 2, fe_select(role == 0, a, b), fe_select(role == 2, c, d));
-}
 ZC_DI pt pt_double_quad(const pt& p, int role)
 {
     // one wave, nothing to overlap with: the independent-chain multiplier has the shorter latency

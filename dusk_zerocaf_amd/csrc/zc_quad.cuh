@@ -1,0 +1,91 @@
+// zc_quad.cuh -- one group-law evaluation shared by a quad of lanes (DPP quad broadcasts).
+// For work that is pure latency: the MSM window combination (zc_msm.cuh) and strict scalar
+// multiplications of batches so small that every SIMD holds a single wave anyway.
+#pragma once
+#include "zc_kernels.cuh"
+
+namespace zc {
+
+template <int J>
+ZC_DI fe quad_bcast(const fe& x)
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.v[i], J * 0x55, 0xF, 0xF, false);
+    return r;
+}
+ZC_DI fe fe_by_role(int role, const fe& a, const fe& b, const fe& c, const fe& d)
+{
+    return fe_select(role < 2, fe_select(role == 0, a, b), fe_select(role == 2, c, d));
+}
+// The unified addition of the scalar-mul loop (ptm_add, zc_curve.cuh) on four lanes that all hold
+// the same operands: phase 1 forms M, P, d*T1 and D on lanes 0..3, lane 2 finishes C = (d T1) T2,
+// phase 2 forms X3 = E F, Y3 = G H, Z3 = F G, T3 = E H.  Three multiplication latencies per step
+// instead of nine; every field value is the one ptm_add computes.
+ZC_DI ptm ptm_add_quad(const ptm& p, const ptm& q, int role)
+{
+    fe m1 = mont_mul_ilp<FP>(fe_by_role(role, p.Ym, p.Yp, p.T, p.Z), fe_by_role(role, q.Ym, q.Yp, fe_const<FP>(ModP::D_M), q.Z));
+    const fe c2 = mont_mul_ilp<FP>(m1, q.T);                 // used by lane 2 only
+    m1 = fe_select(role == 2, c2, m1);
+    const fe M = quad_bcast<0>(m1), P = quad_bcast<1>(m1), C = quad_bcast<2>(m1), D = quad_bcast<3>(m1);
+    const fe E = fe_sub_half<FP>(P, M);
+    const fe H = fe_sub_lazy<FP>(P, E);
+    const fe F = fe_sub_lazy<FP>(D, C);
+    const fe G = fe_add(D, C);
+    const fe m2 = mont_mul_ilp<FP>(fe_by_role(role, E, G, F, E), fe_by_role(role, F, H, G, H));
+    const fe X3 = quad_bcast<0>(m2), Y3 = quad_bcast<1>(m2);
+    ptm r;
+    r.Ym = fp_sub(Y3, X3);
+    r.Yp = fe_add(Y3, X3);
+    r.Z = quad_bcast<2>(m2);
+    r.T = quad_bcast<3>(m2);
+    return r;
+}
+
+// Strict scalar multiplication, four lanes per element (64 elements per workgroup): same loop and
+// same values as scalar_mul_unified, for batches of at most 2^14 elements.
+ZC_KERNEL void k_ed_scalar_mul_quad(const u64* p, const u64* k, u64* out, size_t n)
+{
+    __shared__ u32 sk[9 * (ZC_BLOCK / 4)];
+    const int tid = threadIdx.x, role = tid & 3, slot = tid >> 2;
+    const size_t i = (size_t)blockIdx.x * (ZC_BLOCK / 4) + slot;
+    const bool valid = i < n;
+    const size_t ii = valid ? i : 0;
+    u64 l[5];
+    load5(l, k + 5 * ii);
+    int nbits;
+    {
+        u32 w[9];
+        scalar_to_words(w, 1, l, nbits);                     // every lane of the quad derives the same words
+        if (role == 0) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) sk[j * (ZC_BLOCK / 4) + slot] = w[j];
+        }
+    }
+    __syncthreads();
+    if (!valid) nbits = 0;
+    const u32* words = sk + slot;
+    const int stride = ZC_BLOCK / 4;
+    ptm N = ptm_from_pt(pt_load(p + 20 * ii)), Q = ptm_from_pt(pt_identity());
+    int pos = 0;
+    u32 cur = words[0];
+    bool pend = (cur & 1) != 0;
+    bool active = nbits > 0;
+    while (active) {
+        const ptm lhs = ptm_select(pend, Q, N);
+        const ptm r = ptm_add_quad(lhs, N, role);
+        if (pend) {
+            Q = r;
+            pend = false;
+            active = pos < nbits - 1;
+        } else {
+            N = r;
+            pos++;
+            if ((pos & 31) == 0) cur = words[(pos >> 5) * stride];
+            pend = ((cur >> (pos & 31)) & 1) != 0;
+        }
+    }
+    if (valid && role == 0) pt_store(out + 20 * i, ptm_to_pt(Q));
+}
+
+}  // namespace zc

@@ -332,6 +332,7 @@ const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt)
 // variant with independent column chains (2^16 units: 2.09 -> 1.79 ms; from 384 workgroups on the
 // default kernel is faster again).
 constexpr unsigned SMALL_LAUNCH_BLOCKS = 256;
+constexpr size_t QUAD_LAUNCH_ELEMS = (size_t)1 << 14;     // 4 lanes per element still leave one wave per SIMD
 typedef void (*strict_kernel_t)(const u64*, const u64*, size_t, u64*, const zc::u32*, size_t);
 inline strict_kernel_t strict_kernel_for(size_t cnt)
 {
@@ -343,6 +344,12 @@ int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t*
     Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
         const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
+        if (cnt <= QUAD_LAUNCH_ELEMS && !idx) {
+            // four lanes per element: the batch cannot fill the chip anyway, so buy latency with lanes
+            hipLaunchKernelGGL(zc::k_ed_scalar_mul_quad, dim3((unsigned)((cnt + 63) / 64)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
+                               (const u64*)d[1], (u64*)d[2], cnt);
+            return;
+        }
         hipLaunchKernelGGL(strict_kernel_for(cnt), dim3(grid_for(cnt)),
                            dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (size_t)5, (u64*)d[2], idx, cnt);
     }, true);

@@ -304,6 +304,20 @@ def test_scalar_mul_strict_limbs(eng, oracle, n, bits):
     assert eq(eng.ed_scalar_mul(P, K), oracle.ed_scalar_mul(P, K))
 
 
+@pytest.mark.parametrize("n", [(1 << 14) + 1, 40000, (1 << 16) + 1])
+def test_scalar_mul_strict_launch_shapes(eng, oracle, n):
+    """The strict path picks its kernel by batch size: four lanes per element up to 2^14 (covered
+    above), the independent-chain variant up to 256 workgroups, the default kernel beyond.  The two
+    larger shapes against the oracle on slices (head, middle, ragged tail)."""
+    base = V.base_multiples(oracle, 1500, V.SEED + 44)
+    P = np.tile(base, (n // 1500 + 1, 1))[:n].copy()
+    K = V.rand_scalars_np(n, V.SEED + 45 + n, bits=252)
+    _edge_scalars(K)
+    got = eng.ed_scalar_mul(P, K)
+    sel = np.r_[0:600, n // 2:n // 2 + 600, n - 300:n]
+    assert eq(got[sel], oracle.ed_scalar_mul(P[sel], K[sel]))
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_scalar_mul_reference_variants(eng, oracle, mode):
     """ltr_bin_mul / binary_naf_mul (edwards.rs:122-153): limbs identical to the reference's
