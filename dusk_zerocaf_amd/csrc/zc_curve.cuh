@@ -351,6 +351,34 @@ ZC_DI void pt_store(u64* __restrict__ o, const pt& p)
 }
 
 // ---------------------------------------------------------------- scalar multiplication
+// The scalar double_and_add actually multiplies by.  Its loop test `n != Scalar::zero()`
+// (edwards.rs:111) compares 32-byte encodings (scalar.rs:78-91) and to_bytes drops limb bits
+// >= 256 (backend scalar.rs:477-516), while is_even / half_without_mod (:346, :562-574) walk the
+// whole 260-bit pattern v.  The loop therefore runs T iterations, T = the smallest i with
+// (v >> i) mod 2^256 == 0, and returns (v mod 2^T) * P.  For v < 2^256 that is bitlen(v), i.e.
+// all of v.  For v >= 2^256 with hi = v >> 256 (4 bits): a window [i, i + 256) with i <= 256
+// that misses every set bit of hi needs i <= ctz(hi) and low256 < 2^i, so the loop stops early
+// -- at T = bitlen(low256), leaving low256 * P -- exactly when low256 < 2^ctz(hi); otherwise it
+// runs to bitlen(v) and every bit counts.  Limb bits >= 52 are outside the contract and masked.
+ZC_DI void scalar_effective(u64 (&l)[5])
+{
+#pragma unroll
+    for (int j = 0; j < 5; j++) l[j] &= M52;
+    const u64 low48 = ((u64)1 << 48) - 1;
+    const u32 hi = (u32)(l[4] >> 48);
+    if (hi) {
+        const int tz = __builtin_ctz(hi);
+        const bool stops_early = (l[1] | l[2] | l[3] | (l[4] & low48)) == 0 && l[0] < ((u64)1 << tz);
+        if (stops_early) l[4] &= low48;
+    }
+}
+// Scalar operand of Mul<Scalar> / double_and_add semantics: limbs as given, then the rule above.
+ZC_DI void load_scalar(u64 (&l)[5], const u64* __restrict__ p)
+{
+    load5(l, p);
+    scalar_effective(l);
+}
+
 // Scalar words are read through (sk, stride): word w of this lane is sk[w * stride]
 // (LDS with stride = block size in the kernels, a local array with stride 1 on the host).
 ZC_DI void scalar_to_words(u32* __restrict__ sk, int stride, const u64 (&l)[5], int& nbits)
@@ -439,49 +467,69 @@ ZC_DI pt scalar_mul_ltr(const pt& P, const u32* __restrict__ pos_bits, const u32
 template <int MODE>
 ZC_DI int ltr_digits(u32* __restrict__ pos_bits, u32* __restrict__ neg_bits, int stride, const u64 (&l)[5])
 {
-    u32 w[9];
-    int nb;
-    {
-        u32 tmp[9];
-        scalar_to_words(tmp, 1, l, nb);
-#pragma unroll
-        for (int k = 0; k < 9; k++) w[k] = tmp[k];
-    }
-    u32 pw[8], nw[8];
+    int top = -1;
     if (MODE == 1) {
         // scalar.into_bits() works on to_bytes(): 256 bits; the loop reads bits 248..0 only
-#pragma unroll
-        for (int k = 0; k < 8; k++) { pw[k] = w[k]; nw[k] = 0; }
-        pw[7] &= 0x01FFFFFFu;                              // bits 224..248
-    } else {
-        // non-adjacent form (scalar.rs:370-389; canonical k < L): with x = 3k,
-        // +1 digits = (x & ~k) >> 1, -1 digits = (~x & k) >> 1; digits 0..249 are read
-        u32 x[9];
-        u64 carry = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const u64 dbl = ((u64)w[k] << 1) | (k ? (w[k - 1] >> 31) : 0);
-            const u64 s = (u64)w[k] + (dbl & 0xFFFFFFFFull) + carry;
-            x[k] = (u32)s;
-            carry = s >> 32;
-        }
+        u32 w[9];
+        int nb;
+        scalar_to_words(w, 1, l, nb);
+        w[7] &= 0x01FFFFFFu;                               // bits 224..248
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const u32 p0 = x[k] & ~w[k], p1 = x[k + 1] & ~w[k + 1];
-            const u32 n0 = ~x[k] & w[k], n1 = ~x[k + 1] & w[k + 1];
-            pw[k] = (p0 >> 1) | (p1 << 31);
-            nw[k] = (n0 >> 1) | (n1 << 31);
+            if (w[k]) top = 32 * k + (31 - __builtin_clz(w[k]));
+            pos_bits[k * stride] = w[k];
+            neg_bits[k * stride] = 0;
         }
-        pw[7] &= 0x03FFFFFFu;                              // digits 224..249
-        nw[7] &= 0x03FFFFFFu;
+        return top;
     }
-    int top = -1;
+    // compute_NAF (backend scalar.rs:370-389) step for step on the 260-bit pattern: odd k emits
+    // ki = 2 - (k mod 4) and continues with k - Scalar::from(ki), where Scalar::from(-1) = L - 1
+    // (:67-82) and Sub adds L back only on a borrow (:210-237) -- so k - (L - 1) is k + 1 for
+    // k < L - 1 (the integer NAF: every canonical scalar) and k - L + 1 above; then
+    // half_without_mod.  binary_naf_mul reads digits 249..0 only (edwards.rs:144).
+    u64 k[5], m[5];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const u32 any = pw[k] | nw[k];
-        if (any) top = 32 * k + (31 - __builtin_clz(any));
-        pos_bits[k * stride] = pw[k];
-        neg_bits[k * stride] = nw[k];
+    for (int j = 0; j < 5; j++) k[j] = l[j] & M52;
+    fe_to_limbs52(m, fe_const<ModL>(ModL::N));
+    m[0] -= 1;                                             // L - 1 (L is odd: no borrow)
+    u32 pcur = 0, ncur = 0;
+    for (int i = 0; i < 256; i++) {
+        const bool live = i < 250 && (k[0] | k[1] | k[2] | k[3] | k[4]) != 0;
+        if (live && (k[0] & 1)) {
+            if ((k[0] & 3) == 1) {
+                k[0] -= 1;
+                pcur |= 1u << (i & 31);
+            } else {
+                ncur |= 1u << (i & 31);
+                int c = 0;                                 // sign of k - (L - 1), limb-lexicographic from the top
+#pragma unroll
+                for (int j = 0; j < 5; j++) c = (k[j] > m[j]) ? 1 : ((k[j] < m[j]) ? -1 : c);
+                if (c >= 0) {
+                    u64 borrow = 0;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        borrow = k[j] - (m[j] + (borrow >> 63));
+                        k[j] = borrow & M52;
+                    }
+                } else {
+                    u64 carry = 1;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        carry += k[j];
+                        k[j] = carry & M52;
+                        carry >>= 52;
+                    }
+                }
+            }
+            top = i;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) k[j] = (k[j] >> 1) | (j < 4 ? (k[j + 1] & 1) << 51 : 0);
+        if ((i & 31) == 31) {
+            pos_bits[(i >> 5) * stride] = pcur;
+            neg_bits[(i >> 5) * stride] = ncur;
+            pcur = ncur = 0;
+        }
     }
     return top;
 }

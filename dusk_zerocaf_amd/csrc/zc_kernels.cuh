@@ -410,7 +410,7 @@ ZC_KERNEL void k_sm_cost_hist(const u64* k, u32* hist, size_t n)
     const size_t i = gid();
     if (i < n) {
         u64 l[5];
-        load5(l, k + 5 * i);
+        load_scalar(l, k + 5 * i);
         atomicAdd(&h[scalar_cost(l)], 1u);
     }
     __syncthreads();
@@ -454,7 +454,7 @@ ZC_KERNEL void k_sm_cost_scatter(const u64* k, u32* offsets, u32* idx, size_t n)
     u32 c = 0, rank = 0;
     if (i < n) {
         u64 l[5];
-        load5(l, k + 5 * i);
+        load_scalar(l, k + 5 * i);
         c = scalar_cost(l);
         rank = atomicAdd(&cnt[c], 1u);
     }
@@ -500,6 +500,7 @@ ZC_KERNEL void k_ed_scalar_mul_bcast(const u64* p, scalar_arg k, u64* out, size_
     const size_t i = gid();
     const bool valid = i < n;
     int nbits;
+    scalar_effective(k.l);
     scalar_to_words(sk + tid, ZC_BLOCK, k.l, nbits);
     const pt Q = scalar_mul_unified(pt_load(p + 20 * (valid ? i : 0)), sk + tid, ZC_BLOCK, valid ? nbits : 0);
     if (valid) pt_store(out + 20 * i, Q);
@@ -519,7 +520,7 @@ ZC_DI void ed_scalar_mul_body(const u64* p, const u64* k, size_t k_stride, u64* 
     const bool valid = i < n;
     const size_t own = valid ? (idx ? (size_t)idx[i] : i) : 0;
     u64 l[5];
-    load5(l, k + k_stride * own);
+    load_scalar(l, k + k_stride * own);
     int nbits;
     scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     if (!valid) nbits = 0;
@@ -560,7 +561,7 @@ ZC_KERNEL void k_ed_scalar_mul_fast(const u64* p, const u64* k, size_t k_stride,
     const bool valid = i < n;
     const size_t ii = valid ? i : 0;
     u64 l[5];
-    load5(l, k + k_stride * ii);
+    load_scalar(l, k + k_stride * ii);
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
     top = wave_max_i32(top);
@@ -578,7 +579,7 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
     const size_t ii = valid ? i : 0;
     u64 w[4], l[5];
     load_words256(w, in + 32 * ii);
-    load5(l, k + 5 * ii);
+    load_scalar(l, k + 5 * ii);
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     pt P;
     const bool dec = ris_decompress(P, w);
@@ -653,7 +654,7 @@ ZC_KERNEL void k_ed_mul_base(const u64* k, u64* out, const u32* table, size_t n)
     const size_t i = gid();
     const bool valid = i < n;
     u64 l[5];
-    load5(l, k + 5 * (valid ? i : 0));
+    load_scalar(l, k + 5 * (valid ? i : 0));
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
     top = wave_max_i32(top);
@@ -668,7 +669,7 @@ ZC_KERNEL void k_ris_mul_base_compress(const u64* k, uint8_t* out, const u32* ta
     const size_t i = gid();
     const bool valid = i < n;
     u64 l[5], w[4];
-    load5(l, k + 5 * (valid ? i : 0));
+    load_scalar(l, k + 5 * (valid ? i : 0));
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
     top = wave_max_i32(top);
@@ -780,7 +781,7 @@ ZC_KERNEL_2W void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* 
     const bool valid = i < n;
     const size_t own = valid ? (idx ? (size_t)idx[i] : i) : 0;
     u64 w[4], l[5];
-    load5(l, k + 5 * own);
+    load_scalar(l, k + 5 * own);
     int nbits;
     scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     if (!valid) nbits = 0;

@@ -42,7 +42,7 @@ ZC_KERNEL void k_msm_maxbits(const u64* k, int* maxbits, size_t n)
     int bits = 0;
     if (i < n) {
         u64 l[5];
-        load5(l, k + 5 * i);
+        load_scalar(l, k + 5 * i);
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const u64 x = l[j] & M52;
@@ -59,7 +59,7 @@ ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c,
     const size_t i = gid();
     if (i >= n) return;
     u64 l[5];
-    load5(l, k + 5 * i);
+    load_scalar(l, k + 5 * i);
     for (int w = 0; w < W; w++) {
         keys[(size_t)w * n + i] = ((u32)w << c) | scalar_digit(l, w, c);
         vals[(size_t)w * n + i] = (u32)i;

@@ -52,7 +52,7 @@ ZC_KERNEL void k_ed_scalar_mul_quad(const u64* p, const u64* k, u64* out, size_t
     const bool valid = i < n;
     const size_t ii = valid ? i : 0;
     u64 l[5];
-    load5(l, k + 5 * ii);
+    load_scalar(l, k + 5 * ii);
     int nbits;
     {
         u32 w[9];

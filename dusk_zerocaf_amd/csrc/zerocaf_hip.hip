@@ -413,6 +413,10 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     c -= 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
+    if (const char* e = getenv("ZC_MSM_WINDOW")) {         // test hook: force the window width
+        const int f = atoi(e);
+        if (f >= 4 && f <= 16) c = f;
+    }
     // number of windows from the longest scalar actually present (canonical scalars: 250-253 bits)
     int maxbits = 0;
     {

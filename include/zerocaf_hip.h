@@ -8,8 +8,13 @@
  * the batched form of one reference operation, cited as file:line relative to the
  * reference checkout, and is what a thin Rust `extern "C"` shim binds (see
  * INTEGRATION.md).  Results are bit-identical to the reference on canonical
- * inputs (limbs < 2^52, value < modulus); Scalar operands of scalar-mul may be any
- * 5x52-bit pattern (treated as a plain integer, as double_and_add does).
+ * inputs (limbs < 2^52, value < modulus).  Scalar operands of Mul<Scalar> (zc_ed_scalar_mul,
+ * zc_ris_roundtrip_mul, zc_ed_mul_base, zc_msm ...) may be any pattern of five limbs < 2^52,
+ * i.e. any raw `Scalar([..])`: double_and_add's is_even / half_without_mod walk all 260
+ * bits, and its loop test `n != Scalar::zero()` compares 32-byte encodings (src/scalar.rs:
+ * 78-91 -> to_bytes, src/backend/u64/scalar.rs:477-516), so a pattern v >= 2^256 whose low
+ * 256 bits are below 2^ctz(v >> 256) stops early ([0,0,0,0,1<<50] -> identity,
+ * [1,0,0,0,1<<50] -> P); this is reproduced exactly.  Limb bits >= 2^52 are ignored.
  *
  * Data layout (all arrays contiguous, caller-owned, array-of-structs exactly as
  * the reference's in-memory limbs):
@@ -56,7 +61,9 @@ typedef enum zc_status {
  * three give (X:Y:Z:T) limbs identical to the named reference function.                    */
 #define ZC_SCALAR_MUL_STRICT 0u      /* double_and_add = Mul<Scalar>, src/edwards.rs:102-120     */
 #define ZC_SCALAR_MUL_LTR_BIN 1u     /* ltr_bin_mul, src/edwards.rs:122-134 (reads bits 248..0)  */
-#define ZC_SCALAR_MUL_BINARY_NAF 2u  /* binary_naf_mul, src/edwards.rs:136-153 (canonical k < L) */
+#define ZC_SCALAR_MUL_BINARY_NAF 2u  /* binary_naf_mul, src/edwards.rs:136-153: compute_NAF step for
+                                        step, also above L - 1 where it is not the integer NAF;
+                                        digits >= 256 (reference: index panic) are dropped       */
 /* NOT limb-exact: fixed signed windows + dedicated doubling.  The result is the same group
  * element as Mul<Scalar> (== per src/edwards.rs:360-370, identical compress()/Ristretto bytes);
  * its (X:Y:Z:T) limbs differ by a projective factor.  ~1.5x the strict throughput.          */

@@ -136,9 +136,12 @@ def ed_sub(p1, p2):
 
 
 def ed_scalar_mul(p, k: int):
-    """src/edwards.rs:102-120, including the literal identity + N first add."""
+    """src/edwards.rs:102-120, including the literal identity + N first add.  `k` is the integer the
+    five limbs spell (up to 260 bits for a raw `Scalar([..])`): is_even / half_without_mod see all of
+    it, but the loop test `n != Scalar::zero()` compares 32-byte encodings (src/scalar.rs:78-91), i.e.
+    only the low 256 bits of n (to_bytes, src/backend/u64/scalar.rs:477-516)."""
     n, q = p, IDENT
-    while k != 0:
+    while k % (1 << 256) != 0:
         if k & 1:
             q = ed_add(q, n)
         n = ed_add(n, n)

@@ -19,8 +19,10 @@ extern "C" void zc_bound_fail(const char* what, int line)
 
 using namespace zc;
 
-static pt scalar_mul_seq(const pt& P, const u64 (&l)[5])
+static pt scalar_mul_seq(const pt& P, const u64 (&raw)[5])
 {
+    u64 l[5];
+    load_scalar(l, raw);                                  // as the kernels load their scalar operand
     u32 w[9];
     int nbits;
     scalar_to_words(w, 1, l, nbits);
@@ -106,7 +108,7 @@ void emul_ed_scalar_mul_small(const u64* p, const u64* k, u64* out, size_t n)
 {
     for (size_t i = 0; i < n; i++) {
         u64 l[5];
-        ld5(l, k + 5 * i);
+        load_scalar(l, k + 5 * i);
         u32 w[9];
         int nbits;
         scalar_to_words(w, 1, l, nbits);
@@ -210,10 +212,22 @@ extern "C" void emul_ed_scalar_mul_fast(const u64* p, const u64* k, u64* out, si
 {
     for (size_t i = 0; i < n; i++) {
         u64 l[5];
-        ld5(l, k + 5 * i);
+        load_scalar(l, k + 5 * i);
         alignas(128) u32 table[256];
         int8_t dig[66];
         const int top = scalar_digits16(dig, 1, l);
         pt_store(out + 20 * i, scalar_mul_fast(pt_load(p + 20 * i), table, dig, 1, top));
+    }
+}
+// the termination rule of double_and_add on raw 260-bit patterns (scalar_effective) and the bit
+// length / digit strings the kernels derive from it
+extern "C" void emul_scalar_effective(const u64* k, u64* out, int* nbits, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 l[5];
+        load_scalar(l, k + 5 * i);
+        u32 w[9];
+        scalar_to_words(w, 1, l, nbits[i]);
+        for (int j = 0; j < 5; j++) out[5 * i + j] = l[j];
     }
 }

@@ -67,3 +67,8 @@ def check_backend(be, g):
     out, ok = be.ris_roundtrip_mul(enc, k)
     assert ok.all() and eq(out, u8(rs["roundtrip_mul"]))
     assert eq(be.ris_elligator(u64(rs["elligator_r0"])), u64(rs["elligator"]))
+    rk = g["raw_scalar"]                                              # raw scalars >= 2^256 (early-stopping loop test)
+    rp, rkk = u64(rk["p"]), u64(rk["k"])
+    assert eq(be.ed_scalar_mul(rp, rkk), u64(rk["scalar_mul"]))
+    out, ok = be.ris_roundtrip_mul(be.ris_compress(rp), rkk)
+    assert ok.all() and eq(out, u8(rk["roundtrip_mul"]))

@@ -143,6 +143,55 @@ def test_emul_point_ops(emul, oracle):
     assert np.array_equal(eq, oracle.ed_eq(P, Q)) and eq[2] == 1 and eq[3] == 0
 
 
+def test_emul_raw_scalars_at_or_above_2_256(emul, oracle):
+    """double_and_add's `n != Scalar::zero()` (edwards.rs:111) compares 32-byte encodings, so a raw
+    limb pattern with bits >= 2^256 can stop early: k = [0,0,0,0,1<<50] gives the identity,
+    [1,0,0,0,1<<50] gives P.  The device loop (scalar_effective + scalar_mul_unified), the
+    windowed core and both left-to-right variants must agree with the oracle on every such pattern."""
+    K = V.raw_scalar_edges()
+    n = len(K)
+    P = V.base_multiples(oracle, n, V.SEED + 60)
+    want = oracle.ed_scalar_mul(P, K)
+    ident = np.array(V.IDENT_ROW, dtype=np.uint64)
+    assert np.array_equal(want[0], ident) and np.array_equal(want[7], ident)          # stops at once
+    assert np.array_equal(want[1], oracle.ed_scalar_mul(P[1:2], np.array([[1, 0, 0, 0, 0]], dtype=np.uint64))[0])
+    out, small, fast = np.empty_like(P), np.empty_like(P), np.empty_like(P)
+    emul.emul_ed_scalar_mul(p(P), p(K), p(out), C.c_size_t(n))
+    emul.emul_ed_scalar_mul_small(p(P), p(K), p(small), C.c_size_t(n))
+    assert np.array_equal(out, want) and np.array_equal(small, want)
+    emul.emul_ed_scalar_mul_fast(p(P), p(K), p(fast), C.c_size_t(n))
+    assert oracle.ed_eq(fast, want).all()
+    assert np.array_equal(oracle.ris_compress(fast), oracle.ris_compress(want))
+    for mode in (1, 2):                                         # into_bits / compute_NAF see the raw pattern
+        emul.emul_ed_scalar_mul_mode(p(P), p(K), p(out), C.c_size_t(n), mode)
+        assert np.array_equal(out, oracle.ed_scalar_mul_mode(P, K, mode)), mode
+    # the rule itself against a literal restatement of the loop test on Python integers
+    eff, nbits = np.empty_like(K), np.empty(n, dtype=np.int32)
+    emul.emul_scalar_effective(p(K), p(eff), p(nbits), C.c_size_t(n))
+    for row, e, nb in zip(K, eff, nbits):
+        v, t = pm.from_limbs(row), 0
+        while (v >> t) % (1 << 256) != 0:
+            t += 1
+        assert pm.from_limbs(e) == v % (1 << t) and nb == t, (row, t)
+
+
+def test_emul_naf_noncanonical(emul, oracle):
+    """compute_NAF on scalars in [L - 1, 2^256): `k - Scalar::from(-1)` is k - (L - 1) without the
+    modular wrap there (backend scalar.rs:210-237, :370-389), which is not the integer NAF."""
+    n = 64
+    P = V.base_multiples(oracle, n, V.SEED + 61)
+    K = V.rand_scalars_np(n, V.SEED + 62, bits=256)
+    K[0] = pm.limbs(pm.L - 1)
+    K[1] = pm.limbs(pm.L)
+    K[2] = pm.limbs(pm.L + 2)
+    K[3] = pm.limbs(2 * pm.L - 1)
+    K[4] = pm.limbs(2**250 - 1)
+    K[5] = pm.limbs(2**252 + 3)
+    out = np.empty_like(P)
+    emul.emul_ed_scalar_mul_mode(p(P), p(K), p(out), C.c_size_t(n), 2)
+    assert np.array_equal(out, oracle.ed_scalar_mul_mode(P, K, 2))
+
+
 def test_emul_msm_bucket_sum(emul, oracle):
     n = 300
     P = V.base_multiples(oracle, n, V.SEED + 30)

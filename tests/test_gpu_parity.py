@@ -291,6 +291,9 @@ def _edge_scalars(K):
         K[5] = [0, 0, 0, 0, 1 << 47]
         K[6] = pm.limbs(8)
         K[7] = pm.limbs(pm.L - 1)
+    if len(K) > 64:                                              # raw patterns with bits >= 2^256 (early-stopping loop test)
+        raw = V.raw_scalar_edges()
+        K[8:8 + len(raw)] = raw
 
 
 @pytest.mark.parametrize("n,bits", [(1, 252), (65, 249), (1000, 252), (4096 + 77, 252)])
@@ -316,6 +319,56 @@ def test_scalar_mul_strict_launch_shapes(eng, oracle, n):
     got = eng.ed_scalar_mul(P, K)
     sel = np.r_[0:600, n // 2:n // 2 + 600, n - 300:n]
     assert eq(got[sel], oracle.ed_scalar_mul(P[sel], K[sel]))
+
+
+def test_raw_scalars_at_or_above_2_256(eng, oracle):
+    """`n != Scalar::zero()` (edwards.rs:111) compares 32-byte encodings (scalar.rs:78-91,
+    backend scalar.rs:477-516): raw limb patterns with bits >= 2^256 may stop early --
+    [0,0,0,0,1<<50] -> identity, [1,0,0,0,1<<50] -> P.  Every kernel that takes a Mul<Scalar>
+    operand must follow: the three strict launch shapes, both left-to-right variants, the
+    windowed core, the fused Ristretto round trip, fixed-base multiplication and zc_msm."""
+    import dusk_zerocaf_amd as z
+    raw = V.raw_scalar_edges(n_random=80)
+    ident = np.array([V.IDENT_ROW], dtype=np.uint64)
+    for n in (len(raw), (1 << 14) + 5, (1 << 16) + 300):         # quad / small-launch / default kernels
+        base = V.base_multiples(oracle, len(raw), V.SEED + 160)
+        reps = n // len(raw) + 1
+        P, K = np.tile(base, (reps, 1))[:n].copy(), np.tile(raw, (reps, 1))[:n].copy()
+        got = eng.ed_scalar_mul(P, K)
+        want = oracle.ed_scalar_mul(base, raw)
+        assert eq(got[:len(raw)], want) and eq(got[-len(raw):], np.tile(want, (reps, 1))[:n][-len(raw):])
+        assert eq(got, np.tile(want, (reps, 1))[:n])
+    assert eq(want[0], ident[0]) and eq(want[1], oracle.ed_add(ident, base[1:2])[0])
+    P, K = base, raw
+    for mode in (1, 2):
+        assert eq(eng.ed_scalar_mul(P, K, flags=mode), oracle.ed_scalar_mul_mode(P, K, mode)), mode
+    fast = eng.ed_scalar_mul(P, K, flags=z.FAST)
+    assert oracle.ed_eq(fast, want).all() and eq(oracle.ris_compress(fast), oracle.ris_compress(want))
+    enc = oracle.ris_compress(P)
+    out, ok = eng.ris_roundtrip_mul(enc, K)
+    wout, wok = oracle.ris_roundtrip_mul(enc, K)
+    assert eq(out, wout) and eq(ok, wok)
+    bp = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (len(K), 1))
+    wb = oracle.ed_scalar_mul(bp, K)
+    assert oracle.ed_eq(eng.ed_mul_base(K), wb).all() and eq(eng.ris_mul_base_compress(K), oracle.ris_compress(wb))
+    for n in (len(raw), 6000):                                    # scalar-mul + fold path, bucket path
+        reps = n // len(raw) + 1
+        Pm, Km = np.tile(base, (reps, 1))[:n].copy(), np.tile(raw, (reps, 1))[:n].copy()
+        got, wantm = eng.msm(Pm, Km), oracle.msm_naive_mt(Pm, Km)
+        assert oracle.ed_eq(got, wantm)[0] == 1 and eq(oracle.ed_compress(got)[0], oracle.ed_compress(wantm)[0])
+
+
+def test_naf_noncanonical_scalars(eng, oracle):
+    """compute_NAF above L - 1 is not the integer NAF (k - Scalar::from(-1) does not wrap there,
+    backend scalar.rs:210-237, :370-389); the kernel recodes step for step like the reference."""
+    n = 1000
+    P = V.base_multiples(oracle, n, V.SEED + 161)
+    K = V.rand_scalars_np(n, V.SEED + 162, bits=256)
+    K[0] = pm.limbs(pm.L - 1)
+    K[1] = pm.limbs(pm.L)
+    K[2] = pm.limbs(2 * pm.L - 1)
+    K[3] = pm.limbs(2**252 + 3)
+    assert eq(eng.ed_scalar_mul(P, K, flags=2), oracle.ed_scalar_mul_mode(P, K, 2))
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -379,6 +432,17 @@ def test_scalar_mul_full_size_properties(eng, oracle):
     assert eng.ed_eq(eng.ed_add(r1, r2), rs).all()
     idx = np.arange(0, n, 4099)
     assert eq(rs[idx], oracle.ed_scalar_mul(P[idx], ksum[idx]))
+
+
+def test_scalar_mul_full_size_every_output(eng, oracle):
+    """config 3 exactly as benchmarked: 2^20 distinct points x uniform raw 252-bit scalars, EVERY
+    (X:Y:Z:T) limb of the launch against the oracle (threaded over the host cores)."""
+    n = 1 << 20
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 53, bits=249))     # r_i * B (checked in test_fixed_base_key_generation)
+    K = V.rand_scalars_np(n, V.SEED + 54, bits=252)
+    _edge_scalars(K)
+    got = eng.ed_scalar_mul(P, K)
+    assert eq(got, oracle.mt(oracle.ed_scalar_mul, P, K))
 
 
 def test_codecs_bulk(eng, oracle):
@@ -483,6 +547,10 @@ def test_ristretto_roundtrip_full_size_2_22(eng, oracle):
     idx = np.r_[np.arange(0, n, 8191), bad[:64]]
     wout, wok = oracle.ris_roundtrip_mul(enc[idx], k1[idx])
     assert eq(ok1[idx], wok) and eq(r1[idx], wout)
+    lo = (1 << 21) - (1 << 17)                                    # a contiguous 2^18 slab, invalid rows included
+    slab = slice(lo, lo + (1 << 18))
+    wout, wok = oracle.mt(oracle.ris_roundtrip_mul, enc[slab], k1[slab])
+    assert eq(ok1[slab], wok) and eq(r1[slab], wout) and (wok == 0).sum() > 1000
 
 
 def test_next_rows_elligator_validity_projective(eng, oracle, kats):
@@ -590,8 +658,38 @@ def test_msm_bucket_method(eng, oracle, n, bits):
     K[1] = [1, 0, 0, 0, 0]
     K[2] = [(1 << 52) - 1] * 5                                    # all 260 bits set
     P[3] = V.IDENT_ROW
+    K[4:4 + 24] = V.raw_scalar_edges(n_random=0)                  # bits >= 2^256, early-stopping patterns
     got = eng.msm(P, K)
-    want = oracle.msm_naive(P, K) if n <= 5000 else _gpu_naive_msm(eng, P, K)
+    want = oracle.msm_naive_mt(P, K)                              # the reference's own ops, every size
+    assert oracle.ed_eq(got, want)[0] == 1
+    assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
+    assert eq(oracle.ris_compress(got), oracle.ris_compress(want))
+
+
+def test_msm_window_widths_vs_oracle(eng, oracle, monkeypatch):
+    """Window widths c = 10..16 (forced with ZC_MSM_WINDOW; the natural choice at 2^16 pairs is 12)
+    against the ORACLE's sum of the reference's Mul<Scalar> + Add (edwards.rs:547-561, :465-489)."""
+    n = (1 << 16) + 11
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 87, bits=249))
+    K = V.rand_scalars_np(n, V.SEED + 88, bits=252)
+    K[:24] = V.raw_scalar_edges(n_random=0)
+    P[30] = V.IDENT_ROW
+    want = oracle.msm_naive_mt(P, K)
+    wenc = oracle.ed_compress(want)[0]
+    for c in (10, 12, 13, 14, 15, 16):
+        monkeypatch.setenv("ZC_MSM_WINDOW", str(c))
+        got = eng.msm(P, K)
+        assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), c
+
+
+def test_msm_config5_shard_2_21_vs_oracle(eng, oracle):
+    """The per-GPU shard of BASELINE configs[4] (2^24 pairs over 8 GPUs = 2^21 per GPU), distinct
+    points, S249 scalars, against the oracle's naive sum on all host cores."""
+    n = 1 << 21
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 89, bits=249))
+    K = V.rand_scalars_np(n, V.SEED + 90, bits=249)
+    got = eng.msm(P, K)
+    want = oracle.msm_naive_mt(P, K)
     assert oracle.ed_eq(got, want)[0] == 1
     assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
     assert eq(oracle.ris_compress(got), oracle.ris_compress(want))

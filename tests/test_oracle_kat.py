@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import pymodel as pm
+from tests import vectors as V
 
 ZERO = [0, 0, 0, 0, 0]
 ONE = [1, 0, 0, 0, 0]
@@ -502,3 +503,16 @@ def test_bulk_scalar_mul_and_ristretto_vs_model(oracle):
     w2 = [pm.ris_decompress(r) for r in raw]
     assert ok2.tolist() == [1 if w is not None else 0 for w in w2]
     assert 0 < sum(ok2.tolist()) < 40
+
+
+def test_scalar_mul_raw_patterns_vs_model(oracle):
+    """Raw limb patterns with bits >= 2^256: the C oracle (byte-compare loop test, as the reference)
+    against the independent model (low-256-bit loop test on Python integers)."""
+    K = V.raw_scalar_edges()
+    pts = [pm.ed_scalar_mul(pm.BASEPOINT, 3 + 5 * i) for i in range(len(K))]
+    P = V.pts_np(pts)
+    got = oracle.ed_scalar_mul(P, K)
+    want = V.pts_np([pm.ed_scalar_mul(pt, pm.from_limbs(k)) for pt, k in zip(pts, K)])
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[0], np.array(V.IDENT_ROW, dtype=np.uint64))             # [0,0,0,0,1<<50]
+    assert np.array_equal(got[1], V.pts_np([pm.ed_add(pm.IDENT, pts[1])])[0])           # [1,0,0,0,1<<50]

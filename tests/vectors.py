@@ -58,3 +58,24 @@ def pts_np(pts):
 
 
 IDENT_ROW = [0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+
+
+def raw_scalar_edges(n_random=24, seed=SEED + 0x256):
+    """Raw `Scalar([..])` limb patterns with bits at or above 2^256 (reachable through the pub tuple
+    field, not through from_bytes).  double_and_add's loop test only sees the low 256 bits of n
+    (src/edwards.rs:111 -> src/scalar.rs:78-91 -> src/backend/u64/scalar.rs:477-516), so some of these
+    stop early: [0,0,0,0,1<<50] -> identity, [1,0,0,0,1<<50] -> P, [7,0,0,0,8<<48] -> 7P, while
+    [8,0,0,0,8<<48] or 2^256+5 run all 260 / 257 bits."""
+    t = 1 << 48
+    rows = [[0, 0, 0, 0, 1 << 50], [1, 0, 0, 0, 1 << 50], pm.limbs(2**256 + 5), [2, 0, 0, 0, 2 * t], [1, 0, 0, 0, 2 * t],
+            [7, 0, 0, 0, 8 * t], [8, 0, 0, 0, 8 * t], [0, 0, 0, 0, t], [1, 0, 0, 0, t], [3, 0, 0, 0, 4 * t], [4, 0, 0, 0, 4 * t],
+            [0, 0, 0, 0, 3 * t], [5, 0, 0, 0, 12 * t], [3, 0, 0, 0, 12 * t], [0, 1, 0, 0, 8 * t], [0, 0, 0, 0, 8 * t + 1],
+            [0, 0, 0, 0, 15 * t], [6, 0, 0, 0, 8 * t], [2, 0, 0, 0, 4 * t], [(1 << 52) - 1] * 5, [0, 0, 0, 0, (1 << 52) - 1],
+            [1, 0, 0, 0, 6 * t], [1, 0, 0, 0, 10 * t], [3, 0, 0, 0, 8 * t + (1 << 47)]]
+    rng = np.random.default_rng(seed)
+    rnd = rng.integers(0, 1 << 52, size=(n_random, 5), dtype=np.uint64)
+    rnd[:, 4] |= np.uint64(1) << rng.integers(48, 52, size=n_random).astype(np.uint64)
+    rnd[: n_random // 3, :4] = 0                                # sparse low parts: near the early-stop boundary
+    rnd[: n_random // 3, 4] &= ~np.uint64((1 << 48) - 1)
+    rnd[: n_random // 3, 0] = rng.integers(0, 16, size=n_random // 3, dtype=np.uint64)
+    return np.concatenate([np.array(rows, dtype=np.uint64), rnd])
