@@ -66,9 +66,16 @@ SIGNATURES = {
     "zc_ed_mul_base": [_u64p, _u64p, _n],
     "zc_ris_mul_base_compress": [_u64p, _u8p, _n],
     "zc_msm": [_u64p, _u64p, _n, _u64p],
+    "zc_msm_partial": [_u64p, _u64p, _n, _u64p],
+    "zc_ed_fold_ordered": [_u64p, _n, _u64p],
+    "zc_msm_sharded": [_u64p, _u64p, _n, _u64p],
+    "zc_comm_init": [_u8p, C.c_int, C.c_int],
+    "zc_comm_destroy": [],
+    "zc_ctx_set_stream_dev": [C.c_int, C.c_void_p, C.c_int],
 }
 CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_set_stream", "zc_ctx_synchronize",
-                   "zc_device_count", "zc_last_error", "zc_version"]
+                   "zc_device_count", "zc_last_error", "zc_version", "zc_host_register", "zc_host_unregister",
+                   "zc_comm_unique_id"]
 ALL_SYMBOLS = CONTEXT_SYMBOLS + list(SIGNATURES)
 
 _lib = None
@@ -119,6 +126,9 @@ def load() -> C.CDLL:
     lib.zc_device_count.restype = C.c_int
     lib.zc_last_error.restype = C.c_char_p
     lib.zc_version.restype = C.c_char_p
+    lib.zc_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.zc_host_unregister.argtypes = [C.c_void_p]
+    lib.zc_comm_unique_id.argtypes = [C.c_void_p]
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = [_ctx] + sig

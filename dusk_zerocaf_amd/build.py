@@ -39,5 +39,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """A/B builds of the same ABI with other compile-time knobs: build/variants/<name>.so
+    (load with ZC_LIB_PATH).  Not part of the product; build/ is git-ignored."""
+    out_dir = os.path.join(os.path.dirname(HERE), "build", "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, name + ".so")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
+          ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

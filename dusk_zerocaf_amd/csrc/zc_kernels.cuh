@@ -23,6 +23,19 @@ ZC_DI int wave_max_i32(int v)
     return v;
 }
 
+// maximum over the wave of a small value (-1 <= v < 127) with seven ballots: a binary search on the
+// threshold, all in scalar registers (the shuffle form keeps five lane-address VGPRs alive)
+ZC_DI int wave_max_small(int v)
+{
+    int r = -1;
+#pragma unroll
+    for (int b = 6; b >= 0; b--) {
+        const int t = r + (1 << b);
+        if (__ballot(v >= t) != 0) r = t;
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------ radix-2^52 add/sub
 // Add/Sub/Neg are carry/borrow chains over the reference's own limbs
 // (field.rs:191-240, scalar.rs:184-237); they are done directly in radix 2^52 so the
@@ -321,17 +334,19 @@ ZC_KERNEL void k_from_bytes(const uint8_t* in, u64* out, uint8_t* ok, int check_
     u64 w[4], l[5];
     load_words256(w, in + 32 * i);
     words_to_limbs52(l, w);
-    store5(out + 5 * i, l);
-    if (check_scalar_range && ok) {
-        // assert!(s <= L - 1)  (scalar.rs:465): limb-lexicographic compare from the top
+    if (check_scalar_range) {
+        // assert!(s <= L - 1)  (scalar.rs:465): limb-lexicographic compare from the top; the
+        // reference panics there, here the element comes back as zero with ok = 0
         u64 m[5];
         limbs52_of_modulus<ModL>(m);
         m[0] -= 1;
         int c = 0;                                         // sign of (l - m)
 #pragma unroll
         for (int j = 0; j < 5; j++) c = (l[j] > m[j]) ? 1 : ((l[j] < m[j]) ? -1 : c);
-        ok[i] = (c <= 0) ? 1 : 0;
+        if (c > 0) l[0] = l[1] = l[2] = l[3] = l[4] = 0;
+        if (ok) ok[i] = (c <= 0) ? 1 : 0;
     }
+    store5(out + 5 * i, l);
 }
 ZC_KERNEL void k_to_bytes(const u64* in, uint8_t* out, size_t n)
 {
@@ -553,45 +568,55 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 // line per entry).  ~0.63x the multiplier work of the reference's formula sequence and no SIMT
 // divergence at all.  The result is the same group element as double_and_add's (identical
 // encodings); only its projective (X:Y:Z:T) representative differs.
-ZC_KERNEL void k_ed_scalar_mul_fast(const u64* p, const u64* k, size_t k_stride, u64* out, u32* table, size_t n)
+// `table`: 1 KB of scratch per lane of the launch (8 cached multiples, one cache line each).  The
+// host bounds a launch to FAST_CHUNK_LANES lanes and walks larger batches chunk by chunk on the
+// stream, so the scratch stays at 768 MB however large the batch is.  (A persistent grid -- 768
+// resident workgroups walking the tiles, 192 MB of tables -- was measured 14 % SLOWER, with the table
+// per slot or per tile alike: co-resident waves then start together, stay in lock step and stall on
+// their table loads together; short-lived workgroups drift apart and cover each other.)
+ZC_KERNEL_3W void k_ed_scalar_mul_fast(const u64* p, const u64* k, u32 k_stride, u64* out, u32* table, u32 n)
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
     const int tid = threadIdx.x;
-    const size_t i = gid();
+    const u32 i = blockIdx.x * ZC_BLOCK + tid;             // a launch is at most FAST_CHUNK_LANES elements
     const bool valid = i < n;
-    const size_t ii = valid ? i : 0;
+    const u32 ii = valid ? i : 0;
     u64 l[5];
     load_scalar(l, k + k_stride * ii);
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
-    top = wave_max_i32(top);
-    const pt Q = scalar_mul_fast(pt_load(p + 20 * ii), table + 256 * gid(), sdig + tid, ZC_BLOCK, top);
-    if (valid) pt_store(out + 20 * i, Q);
+    top = wave_max_small(top);
+    const pt Q = scalar_mul_fast(pt_load(p + 20 * (size_t)ii), table + 256 * (size_t)i, sdig + tid, ZC_BLOCK, top);
+    if (valid) pt_store(out + 20 * (size_t)i, Q);
 }
 // fused config-4 path on the fast core: the boundary is bytes in / bytes out, and a Ristretto
 // encoding depends only on the group element, so the outputs stay bit-identical to the reference
-ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, u32* table, size_t n)
+ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, u32* table, u32 n)
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
     const int tid = threadIdx.x;
-    const size_t i = gid();
+    const u32 i = blockIdx.x * ZC_BLOCK + tid;             // a launch is at most FAST_CHUNK_LANES elements
     const bool valid = i < n;
-    const size_t ii = valid ? i : 0;
+    const u32 ii = valid ? i : 0;
     u64 w[4], l[5];
-    load_words256(w, in + 32 * ii);
-    load_scalar(l, k + 5 * ii);
+    load_words256(w, in + 32 * (size_t)ii);
+    load_scalar(l, k + 5 * (size_t)ii);
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     pt P;
     const bool dec = ris_decompress(P, w);
     if (!valid || !dec) top = -1;
-    top = wave_max_i32(top);
-    pt Q = scalar_mul_fast(P, table + 256 * gid(), sdig + tid, ZC_BLOCK, top);
+    top = wave_max_small(top);
+    pt Q = scalar_mul_fast(P, table + 256 * (size_t)i, sdig + tid, ZC_BLOCK, top);
     Q = pt_select(dec, Q, pt_identity());
     fe_to_words256(w, ris_compress(Q));
     if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
-    if (valid) {
-        store_words256(out + 32 * i, w);
-        if (ok) ok[i] = dec ? 1 : 0;
+    // the output address is formed here, from the hardware ids again, instead of staying live (as a
+    // 64-bit pair the register allocator would spill) across the three exponentiation-sized phases
+    u32 i_late = blockIdx.x * ZC_BLOCK + threadIdx.x;
+    asm volatile("" : "+v"(i_late));
+    if (i_late < n) {
+        store_words256(out + 32 * (size_t)i_late, w);
+        if (ok) ok[i_late] = dec ? 1 : 0;
     }
 }
 
@@ -657,7 +682,7 @@ ZC_KERNEL void k_ed_mul_base(const u64* k, u64* out, const u32* table, size_t n)
     load_scalar(l, k + 5 * (valid ? i : 0));
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
-    top = wave_max_i32(top);
+    top = wave_max_small(top);
     const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
     if (valid) pt_store(out + 20 * i, Q);
 }
@@ -672,7 +697,7 @@ ZC_KERNEL void k_ris_mul_base_compress(const u64* k, uint8_t* out, const u32* ta
     load_scalar(l, k + 5 * (valid ? i : 0));
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
-    top = wave_max_i32(top);
+    top = wave_max_small(top);
     const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
     fe_to_words256(w, ris_compress(Q));
     if (valid) store_words256(out + 32 * i, w);
@@ -898,6 +923,19 @@ ZC_KERNEL void k_ed_fold_pairs(const u64* in, u64* out, size_t n_in)
     const pt a = pt_load(in + 20 * (2 * i));
     if (2 * i + 1 < n_in) pt_store(out + 20 * i, pt_add(a, pt_load(in + 20 * (2 * i + 1))));
     else pt_store(out + 20 * i, a);
+}
+
+// ((p0 + p1) + p2) + ... in index order with the unified addition (edwards.rs:465-489), one
+// launch: the exchange step of a sharded MSM folds the gathered per-rank partials with this, so
+// every rank ends with identical limbs.  `count` is small (one point per GPU); a single lane on
+// the independent-chain multiplier.  `extra` (optional) is added last.
+ZC_KERNEL void k_ed_fold_ordered(const u64* parts, size_t count, const u64* extra, u64* out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    pt acc = count ? pt_load(parts) : pt_identity();
+    for (size_t i = 1; i < count; i++) acc = pt_add<true>(acc, pt_load(parts + 20 * i));
+    if (extra) acc = pt_add<true>(acc, pt_load(extra));
+    pt_store(out, acc);
 }
 
 }  // namespace zc

@@ -1,57 +1,55 @@
 // zc_msm.cuh -- bucket-method (Pippenger) multi-scalar multiplication kernels.
 // Not in the reference: sum_i k_i * P_i is specified through the reference's
-// own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU:
-//   1. k_msm_digits   : c-bit window digits -> (key = window << c | digit, value = point index)
-//   2. rocPRIM radix sort of the n*W pairs by key (c + log2 W bits)
-//   3. k_msm_bounds   : [start, end) of every bucket in the sorted list
+// own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU, one stream,
+// no host synchronisation anywhere:
+//   1. k_msm_digits   : SIGNED c-bit window digits d in (-2^(c-1), 2^(c-1)] of the effective scalar
+//                       (scalar_effective: double_and_add's termination rule) ->
+//                       (key = window << (c-1) | |d| - 1, value = point index | sign << 31);
+//                       zero digits get the sentinel key W << (c-1), which sorts behind every bucket.
+//                       W = ceil(261 / c) windows hold any 260-bit pattern plus the last carry, so the
+//                       window count never depends on the data (empty windows cost empty buckets only).
+//   2. rocPRIM radix sort of the n*W pairs by key
 //   0. k_msm_prepare  : points -> cached form (Y-X, Y+X, Z, 2dT), Montgomery domain, packed to
 //                       one 128-byte cache line per point
-//   4. k_msm_counts + rocPRIM sort of the bucket ids by population (descending), then
-//      k_msm_accumulate: one lane per bucket, lanes of a wave get equally full buckets; each
-//      point costs one 8-multiplication a = -1 addition against the cached form; the next
-//      record is prefetched straight into LDS (global_load_lds), four waves per SIMD
+//   3. k_msm_runs     : the bucket sums as a SEGMENTED REDUCTION of the sorted list in fixed-length
+//                       runs: lane j adds the T consecutive entries [jT, (j+1)T) whatever buckets they
+//                       belong to, so every lane does the same work however skewed the digit
+//                       distribution is (a window whose top bits are always zero has a few buckets
+//                       with n / 2^k points each; one lane per bucket would serialise them).  A bucket
+//                       that lies inside one run is written out directly; a bucket that crosses run
+//                       boundaries leaves one partial sum per run ("edge"), and the edge list -- again
+//                       sorted by key, 2 n W / T entries -- goes through the same kernel until one lane
+//                       holds it all (list lengths shrink by T/2 per level: 6 launches for 2^25 pairs).
+//                       Each point costs one 8-multiplication a = -1 addition against the cached form
+//                       (negated by swapping Y-X / Y+X and negating 2dT when the digit is negative); the
+//                       next record is prefetched straight into LDS (global_load_lds), four waves per SIMD
 //   5. k_msm_segments : running-sum reduction of each window in segments of SEG buckets
-//                       (sum_seg = sum (d - lo + 1) B_d, acc_seg = sum B_d)
-//   6. existing kernels: (lo - 1) * acc_seg via k_ed_scalar_mul, k_ed_add, k_ed_fold_pairs down
-//      to one point per window
+//                       (sum_seg = sum (j + 1) B_{first+j}, acc_seg = sum B)
+//   6. existing kernels: (first mod 2^(c-1)) * acc_seg via k_ed_scalar_mul, k_ed_add,
+//      k_ed_fold_pairs down to one point per window
 //   7. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling
 #pragma once
 #include "zc_kernels.cuh"
 #include "zc_quad.cuh"
 
+#ifndef ZC_MSM_ACC_ILP
+#define ZC_MSM_ACC_ILP true    // bucket sums on the independent-chain multiplier (A/B knob)
+#endif
+
 namespace zc {
 
 constexpr int MSM_SEG = 16;   // buckets per reduction segment
+constexpr int MSM_SCALAR_BITS = 261;   // 260-bit limb patterns + the carry of the signed recoding
+constexpr int MSM_MIN_C = 5, MSM_MAX_C = 22;
 
-// digit w of the 260-bit scalar (5 x 52-bit limbs), c <= 16
-ZC_DI u32 scalar_digit(const u64 (&l)[5], int w, int c)
+// c bits of the 260-bit scalar starting at bit `bit` (5 x 52-bit limbs), c <= 32
+ZC_DI u32 scalar_bits(const u64 (&l)[5], int bit, int c)
 {
-    const int bit = w * c;
     const int idx = bit / 52, sh = bit % 52;
     if (idx >= 5) return 0;
-    u64 x = (l[idx] & M52) >> sh;
-    if (sh + c > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - sh);
-    return (u32)x & ((1u << c) - 1);
-}
-
-// largest scalar bit length of the shard (wave reduce, at most one atomicMax per wave): windows above it
-// hold only zero digits and are not generated at all
-ZC_KERNEL void k_msm_maxbits(const u64* k, int* maxbits, size_t n)
-{
-    const size_t i = gid();
-    int bits = 0;
-    if (i < n) {
-        u64 l[5];
-        load_scalar(l, k + 5 * i);
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const u64 x = l[j] & M52;
-            if (x) bits = 52 * j + (64 - __builtin_clzll(x));
-        }
-    }
-    bits = wave_max_i32(bits);
-    // almost every wave sees the batch maximum: look before the (serialised) atomic
-    if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, bits);
+    u64 x = l[idx] >> sh;
+    if (sh + c > 52 && idx + 1 < 5) x |= l[idx + 1] << (52 - sh);
+    return (u32)x & (u32)(((u64)1 << c) - 1);
 }
 
 ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c, int W)
@@ -60,20 +58,15 @@ ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c,
     if (i >= n) return;
     u64 l[5];
     load_scalar(l, k + 5 * i);
+    const u32 half = 1u << (c - 1), sentinel = (u32)W << (c - 1);
+    u32 carry = 0;
     for (int w = 0; w < W; w++) {
-        keys[(size_t)w * n + i] = ((u32)w << c) | scalar_digit(l, w, c);
-        vals[(size_t)w * n + i] = (u32)i;
+        const u32 raw = scalar_bits(l, w * c, c) + carry;              // 0 .. 2^c
+        carry = raw > half ? 1u : 0u;                                    // digit = raw - carry * 2^c
+        const u32 mag = carry ? (1u << c) - raw : raw;                   // |digit| in 0 .. 2^(c-1)
+        keys[(size_t)w * n + i] = mag ? (((u32)w << (c - 1)) | (mag - 1)) : sentinel;
+        vals[(size_t)w * n + i] = (u32)i | (carry << 31);
     }
-}
-
-// start[key] / end[key] for every key present in the sorted list (arrays pre-zeroed)
-ZC_KERNEL void k_msm_bounds(const u32* keys, u32* start, u32* end, size_t m)
-{
-    const size_t j = gid();
-    if (j >= m) return;
-    const u32 key = keys[j];
-    if (j == 0 || keys[j - 1] != key) start[key] = (u32)j;
-    if (j + 1 == m || keys[j + 1] != key) end[key] = (u32)(j + 1);
 }
 
 // Cached ("projective Niels") form of an input point for the bucket sums: (Y-X, Y+X, Z, 2dT),
@@ -87,48 +80,111 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
     if (i >= n) return;
     niels_store(cached + 32 * i, niels_from_pt(pt_load(points + 20 * i)));
 }
-// population of every bucket (0 for digit 0, which carries no weight) and its id
-ZC_KERNEL void k_msm_counts(const u32* start, const u32* end, u32* count, u32* ids, size_t nbuckets, int c)
+// Bucket sums are kept in the kernels' own number system between k_msm_runs and k_msm_segments:
+// 36 x u32 (X, Y, Z, T as nine 29-bit Montgomery limbs each, R-class), 144 bytes per bucket.  The
+// array is zero-filled first; Z == 0 never occurs for a point, so an all-zero record reads as the
+// identity (an empty bucket).
+constexpr int MSM_RAW_WORDS = 36;
+ZC_DI void pt_store_raw(u32* __restrict__ o, const pt& p)
 {
-    const size_t b = gid();
-    if (b >= nbuckets) return;
-    count[b] = ((b & ((1u << c) - 1)) != 0) ? end[b] - start[b] : 0;
-    ids[b] = (u32)b;
+    uint4* v = reinterpret_cast<uint4*>(o);               // 144-byte records: 16-byte aligned
+    const u32 w[36] = {p.X.v[0], p.X.v[1], p.X.v[2], p.X.v[3], p.X.v[4], p.X.v[5], p.X.v[6], p.X.v[7], p.X.v[8],
+                       p.Y.v[0], p.Y.v[1], p.Y.v[2], p.Y.v[3], p.Y.v[4], p.Y.v[5], p.Y.v[6], p.Y.v[7], p.Y.v[8],
+                       p.Z.v[0], p.Z.v[1], p.Z.v[2], p.Z.v[3], p.Z.v[4], p.Z.v[5], p.Z.v[6], p.Z.v[7], p.Z.v[8],
+                       p.T.v[0], p.T.v[1], p.T.v[2], p.T.v[3], p.T.v[4], p.T.v[5], p.T.v[6], p.T.v[7], p.T.v[8]};
+#pragma unroll
+    for (int q = 0; q < 9; q++) v[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+ZC_DI pt pt_load_raw(const u32* __restrict__ o)
+{
+    const uint4* v = reinterpret_cast<const uint4*>(o);
+    u32 w[36];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const uint4 x = v[q];
+        w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+    }
+    pt p;
+    u32 zor = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        p.X.v[i] = w[i]; p.Y.v[i] = w[9 + i]; p.Z.v[i] = w[18 + i]; p.T.v[i] = w[27 + i];
+        zor |= w[18 + i];
+    }
+    return pt_select(zor == 0, pt_identity(), p);
 }
 
-// buckets[b] = sum of the points whose (window, digit) == b.  `order` lists the bucket ids by
-// descending population so the 64 lanes of a wave run (almost) the same trip count.
-// The (random) 128-byte gather of point e+1 is in flight while point e is being added, and it
+ZC_DI void raw_store_zero(u32* __restrict__ o)
+{
+    uint4* v = reinterpret_cast<uint4*>(o);
+#pragma unroll
+    for (int q = 0; q < 9; q++) v[q] = make_uint4(0, 0, 0, 0);
+}
+// End of a segment (maximal stretch of one key inside a run): where does its sum go?
+//   * a segment that neither starts the run with the previous run's last key nor ends it with the
+//     next run's first key is a whole bucket -> buckets_raw[key];
+//   * otherwise it becomes an edge of the next level, in the same raw format: slot 2j (open to the
+//     left) or 2j + 1 (open to the right only); a run that is one segment open on both sides fills
+//     both slots (the second with an all-zero record = identity) so that no unused slot ever
+//     separates two edges of one bucket.  Unused slots keep the sentinel key the host pre-filled
+//     (0xFFFFFFFF >= nbuckets); zero digits carry a sentinel key too and are dropped here.
+ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 prev_key, u32 next_key, u32 j, u32 nbuckets,
+                     u32* __restrict__ buckets_raw, u32* __restrict__ next_keys, u32* __restrict__ next_recs)
+{
+    if (key >= nbuckets) return;
+    const bool open_left = seg_first && key == prev_key;
+    const bool open_right = seg_last && key == next_key;
+    u32* dst = buckets_raw + MSM_RAW_WORDS * (size_t)key;
+    if (open_left || open_right) {
+        const size_t slot = open_left ? 2 * (size_t)j : 2 * (size_t)j + 1;
+        next_keys[slot] = key;
+        dst = next_recs + MSM_RAW_WORDS * slot;
+        if (open_left && open_right) {
+            next_keys[slot + 1] = key;
+            raw_store_zero(dst + MSM_RAW_WORDS);
+        }
+    }
+    pt_store_raw(dst, sum);
+}
+
+// Level 0 of the segmented reduction (see the file header): the sorted (key, point index | sign << 31)
+// pairs, gathering the prepared 128-byte cached records.  Lane j owns the run [j T, (j + 1) T).
+// The (random) 128-byte gather of entry e+1 is in flight while entry e is being added, and it
 // lands in LDS, not in registers: `global_load_lds_dwordx4` copies 16 bytes per lane straight into
-// the wave's staging area (piece j of all 64 lanes contiguous: M0 = base + j KB), so the prefetch
+// the wave's staging area (piece q of all 64 lanes contiguous: M0 = base + q KB), so the prefetch
 // holds no VGPRs and the kernel fits four waves per SIMD (32 KB of LDS per block, 4 blocks per CU).
 // A lane reads and overwrites only its own slots: lgkmcnt(0) before the next copy is issued,
 // vmcnt(0) before the slots are read.
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
-void k_msm_accumulate(const u32* cached, const u32* vals, const u32* start, const u32* end, const u32* order,
-                      u64* buckets, size_t nbuckets, int c)
+void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                u32* buckets_raw, u32* next_keys, u32* next_recs)
 {
     __shared__ uint4 stage[8 * ZC_BLOCK];
     const int lane = threadIdx.x & 63;
     uint4* base = stage + (threadIdx.x >> 6) * (8 * 64);
-    const size_t j = gid();
-    const bool valid = j < nbuckets;
-    const size_t b = valid ? order[j] : 0;
-    u32 lo = 0, hi = 0;
-    if (valid && (b & ((1u << c) - 1)) != 0) {
-        lo = start[b];
-        hi = end[b];
-    }
-    auto fetch = [&](u32 idx) {
-        const uint4* src = reinterpret_cast<const uint4*>(cached + 32 * (size_t)idx);
+    const u32 j = blockIdx.x * ZC_BLOCK + threadIdx.x;
+    const u64 lo64 = (u64)j * T;
+    if (lo64 >= len) return;
+    const u32 lo = (u32)lo64;
+    const u32 hi = (len - lo > T) ? lo + T : len;
+    const u32 none = 0xFFFFFFFFu;
+    u32 cur_key = keys[lo];
+    if (cur_key >= nbuckets) return;                           // zero digits sort behind every bucket: nothing to add
+    const u32 prev_key = lo > 0 ? keys[lo - 1] : none;
+    const u32 next_key = hi < len ? keys[hi] : none;
+    auto fetch = [&](u32 v) {
+        const uint4* src = reinterpret_cast<const uint4*>(recs + 32 * (size_t)(v & 0x7FFFFFFFu));
 #pragma unroll
         for (int q = 0; q < 8; q++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q),
                                              (__attribute__((address_space(3))) void*)(base + q * 64), 16, 0, 0);
     };
     pt acc = pt_identity();
-    if (lo < hi) fetch(vals[lo]);
-    u32 inext = (lo + 1 < hi) ? vals[lo + 1] : 0;
+    u32 vcur = idx[lo];
+    fetch(vcur);
+    u32 vnext = (lo + 1 < hi) ? idx[lo + 1] : 0;
+    u32 knext = (lo + 1 < hi) ? keys[lo + 1] : none;
+    bool first = true;
     for (u32 e = lo; e < hi; e++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         niels cur;
@@ -137,34 +193,75 @@ void k_msm_accumulate(const u32* cached, const u32* vals, const u32* start, cons
         cur.z = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
         cur.t2d = unpack256(base[6 * 64 + lane], base[7 * 64 + lane]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (e + 1 < hi) fetch(inext);
-        inext = (e + 2 < hi) ? vals[e + 2] : 0;
-        acc = pt_add_cached<true>(acc, cur);
+        const bool neg = (vcur >> 31) != 0;
+        if (e + 1 < hi) fetch(vnext);
+        vcur = vnext;
+        vnext = (e + 2 < hi) ? idx[e + 2] : 0;
+        acc = pt_add_cached<ZC_MSM_ACC_ILP>(acc, niels_cond_neg(neg, cur));
+        const bool last = e + 1 == hi;
+        if (last || knext != cur_key) {                        // the segment ends with this entry
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, next_keys, next_recs);
+            acc = pt_identity();
+            first = false;
+            cur_key = knext;
+            if (cur_key >= nbuckets) break;                    // only zero digits follow
+        }
+        knext = (e + 2 < hi) ? keys[e + 2] : none;
     }
-    if (valid) pt_store(buckets + 20 * b, acc);
 }
 
-// One lane per segment of MSM_SEG consecutive buckets [lo, lo + SEG) of one window:
-//   acc = sum_d B_d,  sum = sum_d (d - lo + 1) B_d   (running sums from the top bucket down)
-// so that  sum_d d * B_d = sum + (lo - 1) * acc.  Emits sum, acc and the scalar (lo - 1) >= 0.
-ZC_KERNEL void k_msm_segments(const u64* buckets, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c)
+// Levels >= 1: the edge list of the level above (raw 144-byte records in list order, sentinel keys in
+// unused slots), same run / segment rules, full unified additions.  A few per cent of level 0's work.
+// Runs are shifted by one entry (run 0 = [0, T + 1), run j = [j T + 1, (j + 1) T + 1)): a bucket cut once
+// at the level above left its two edges in slots 2j + 1 and 2j + 2, and with an even T that pair always
+// lies inside one run here, so everything but the buckets longer than a run is finished at level 1.
+ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                                u32* buckets_raw, u32* next_keys, u32* next_recs)
+{
+    const u32 j = blockIdx.x * ZC_BLOCK + threadIdx.x;
+    const u64 lo64 = j ? (u64)j * T + 1 : 0;
+    if (lo64 >= len) return;
+    const u32 lo = (u32)lo64;
+    const u64 hi64 = (u64)(j + 1) * T + 1;
+    const u32 hi = hi64 < len ? (u32)hi64 : len;
+    const u32 none = 0xFFFFFFFFu;
+    const u32 prev_key = lo > 0 ? keys[lo - 1] : none;
+    const u32 next_key = hi < len ? keys[hi] : none;
+    pt acc = pt_identity();
+    u32 cur_key = keys[lo];
+    bool first = true;
+    for (u32 e = lo; e < hi; e++) {
+        if (cur_key < nbuckets) acc = pt_add<true>(acc, pt_load_raw(recs + MSM_RAW_WORDS * (size_t)e));
+        const bool last = e + 1 == hi;
+        const u32 knext = last ? none : keys[e + 1];
+        if (last || knext != cur_key) {
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, next_keys, next_recs);
+            acc = pt_identity();
+            first = false;
+            cur_key = knext;
+        }
+    }
+}
+
+// One lane per segment of MSM_SEG consecutive buckets [first, first + SEG) of one window (bucket
+// index b of a window holds the digit magnitude b + 1):
+//   acc = sum_j B_{first+j},  sum = sum_j (j + 1) B_{first+j}   (running sums from the top bucket down)
+// so that  sum_j (first' + j + 1) B_{first+j} = sum + first' * acc  with first' = first mod 2^(c-1).
+// Emits sum, acc and the scalar first'.
+ZC_KERNEL void k_msm_segments(const u32* buckets_raw, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c)
 {
     const size_t s = gid();
     if (s >= nseg_total) return;
     const size_t first = s * MSM_SEG;                     // global bucket index of the segment start
-    const u32 lo = (u32)(first & ((1u << c) - 1));        // digit value of the first bucket
     pt acc = pt_identity(), sum = pt_identity();
-    // the lo == 0 segment stops above bucket 0 (digit 0 carries no weight): its running sum is
-    // already sum_d d * B_d and its scalar is 0
-    const int jmin = (lo == 0) ? 1 : 0;
-    for (int j = MSM_SEG - 1; j >= jmin; j--) {
-        acc = pt_add<true>(acc, pt_load(buckets + 20 * (first + j)));
+    for (int j = MSM_SEG - 1; j >= 0; j--) {
+        acc = pt_add<true>(acc, pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j)));
         sum = pt_add<true>(sum, acc);
     }
     pt_store(seg_sum + 20 * s, sum);
     pt_store(seg_acc + 20 * s, acc);
     u64* k = seg_scalar + 5 * s;
-    k[0] = (lo == 0) ? 0 : lo - 1;
+    k[0] = (u64)(first & (((size_t)1 << (c - 1)) - 1));
     k[1] = 0; k[2] = 0; k[3] = 0; k[4] = 0;
 }
 

@@ -10,7 +10,11 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: librccl is opened with dlopen when a communicator is requested
 
 #include "../../include/zerocaf_hip.h"
 #include "zc_kernels.cuh"
@@ -44,6 +48,7 @@ constexpr int MAX_ARGS = 6;
 
 struct DevState {
     int device = 0;
+    int cus = 256;                      // compute units (multiProcessorCount)
     hipStream_t stream = nullptr;       // owned
     hipStream_t borrowed = nullptr;     // set by zc_ctx_set_stream (device 0 only)
     bool use_borrowed = false;
@@ -58,11 +63,28 @@ struct DevState {
     size_t bal_bytes = 0;
     void* msm = nullptr;                // bucket-method workspace (zc_msm)
     size_t msm_bytes = 0;
-    void* fast = nullptr;               // fast scalar-mul window tables: 1 KB per lane
+    void* fast = nullptr;               // fast scalar-mul window tables: 1 KB per lane of a chunk
     size_t fast_bytes = 0;
+    void* fast2 = nullptr;              // the second chunk in flight (alternate chunks run on `aux`)
+    size_t fast2_bytes = 0;
+    hipStream_t aux = nullptr;          // forked from / joined to the launch stream with events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* base_table = nullptr;         // comb table of the basepoint: 66 x 8 cached points
     size_t base_bytes = 0;
+    void* part = nullptr;               // MSM exchange: gathered per-rank / per-device partials + the folded result
+    size_t part_bytes = 0;
+    hipEvent_t ev_order = nullptr;      // orders work across a stream switch / across devices
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
+};
+
+// librccl entry points (resolved at zc_comm_init; the library has no link-time dependency on RCCL)
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
 }  // namespace
@@ -70,6 +92,8 @@ struct DevState {
 struct zc_ctx {
     std::vector<DevState> devs;
     std::mutex mu;
+    ncclComm_t comm = nullptr;          // zc_comm_init: one rank per process, device 0 of the context
+    int rank = 0, world = 1;
 };
 
 namespace {
@@ -179,93 +203,97 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bo
     }
 
     // host buffers: shard into contiguous ranges, one per device (no exchange step); each range
-    // moves through the device in chunks so uploads, kernels and downloads overlap
+    // moves through its device in chunks so uploads, kernels and downloads overlap.  Copies from /
+    // to pageable memory block the issuing thread, so every device gets its own worker thread:
+    // the devices' uploads proceed side by side instead of one after the other (buffers pinned
+    // with zc_host_register copy asynchronously in any case).
     const size_t ndev = ctx->devs.size();
     const size_t per = (n + ndev - 1) / ndev;
 
-    struct Plan {
-        size_t lo = 0, cnt = 0, chunk = 0, nchunks = 0;
-        void* base[MAX_ARGS] = {};
+    auto device_job = [&](size_t di, std::string* err) -> int {
+        const size_t lo = di * per, hi = std::min(n, lo + per);
+        if (lo >= hi) return ZC_OK;
+        const size_t total = hi - lo;
+        const size_t chunk = host_chunk_elems(total, heavy);
+        const size_t nchunks = (total + chunk - 1) / chunk;
+        DevState& ds = ctx->devs[di];
+        auto body = [&]() -> int {
+            HIP_TRY(hipSetDevice(ds.device));
+            void* base[MAX_ARGS] = {};
+            for (int a = 0; a < nargs; a++) {
+                if (!args[a].ptr) continue;
+                int rc = ensure(&ds.scratch[a], &ds.scratch_bytes[a], args[a].elt_bytes * total);
+                if (rc) return rc;
+                base[a] = ds.scratch[a];
+            }
+            while (ds.ev.size() < 2 * nchunks) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ds.ev.push_back(e);
+            }
+            // chunk j: upload on copy_in, kernel on the context stream, download on copy_out
+            auto upload_and_launch = [&](size_t j) -> int {
+                if (j >= nchunks) return ZC_OK;
+                const size_t off = j * chunk, cnt = std::min(chunk, total - off);
+                void* dptr[MAX_ARGS];
+                for (int a = 0; a < nargs; a++) {
+                    dptr[a] = base[a] ? (char*)base[a] + args[a].elt_bytes * off : nullptr;
+                    if (!args[a].ptr || args[a].is_out) continue;
+                    const char* src = (const char*)args[a].ptr + args[a].elt_bytes * (lo + off);
+                    HIP_TRY(hipMemcpyAsync(dptr[a], src, args[a].elt_bytes * cnt, hipMemcpyHostToDevice, ds.copy_in));
+                }
+                HIP_TRY(hipEventRecord(ds.ev[2 * j], ds.copy_in));
+                HIP_TRY(hipStreamWaitEvent(ds.s(), ds.ev[2 * j], 0));
+                launch(dptr, cnt, ds);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(ds.ev[2 * j + 1], ds.s()));
+                return ZC_OK;
+            };
+            auto download = [&](size_t j) -> int {
+                const size_t off = j * chunk, cnt = std::min(chunk, total - off);
+                HIP_TRY(hipStreamWaitEvent(ds.copy_out, ds.ev[2 * j + 1], 0));
+                for (int a = 0; a < nargs; a++) {
+                    if (!args[a].ptr || !args[a].is_out) continue;
+                    char* dst = (char*)const_cast<void*>(args[a].ptr) + args[a].elt_bytes * (lo + off);
+                    HIP_TRY(hipMemcpyAsync(dst, (char*)base[a] + args[a].elt_bytes * off, args[a].elt_bytes * cnt, hipMemcpyDeviceToHost, ds.copy_out));
+                }
+                return ZC_OK;
+            };
+            // keep LOOKAHEAD kernels queued before the thread blocks on a download
+            constexpr size_t LOOKAHEAD = 2;
+            int rc = ZC_OK;
+            for (size_t j = 0; j < std::min(LOOKAHEAD, nchunks) && !rc; j++) rc = upload_and_launch(j);
+            for (size_t j = 0; j < nchunks && !rc; j++) {
+                rc = download(j);
+                if (!rc) rc = upload_and_launch(j + LOOKAHEAD);
+            }
+            HIP_TRY(hipStreamSynchronize(ds.copy_in));
+            HIP_TRY(hipStreamSynchronize(ds.s()));
+            HIP_TRY(hipStreamSynchronize(ds.copy_out));
+            return rc;
+        };
+        const int rc = body();
+        if (rc && err) *err = g_last_error;                 // thread-local: hand the message to the caller's thread
+        return rc;
     };
-    std::vector<Plan> plans(ndev);
-    size_t max_chunks = 0;
-    for (size_t di = 0; di < ndev; di++) {
-        Plan& pl = plans[di];
-        pl.lo = di * per;
-        const size_t hi = std::min(n, pl.lo + per);
-        if (pl.lo >= hi) break;
-        pl.cnt = hi - pl.lo;
-        pl.chunk = host_chunk_elems(pl.cnt, heavy);
-        pl.nchunks = (pl.cnt + pl.chunk - 1) / pl.chunk;
-        max_chunks = std::max(max_chunks, pl.nchunks);
-        DevState& ds = ctx->devs[di];
-        HIP_TRY(hipSetDevice(ds.device));
-        for (int a = 0; a < nargs; a++) {
-            if (!args[a].ptr) continue;
-            int rc = ensure(&ds.scratch[a], &ds.scratch_bytes[a], args[a].elt_bytes * pl.cnt);
-            if (rc) return rc;
-            pl.base[a] = ds.scratch[a];
-        }
-        while (ds.ev.size() < 2 * pl.nchunks) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ds.ev.push_back(e);
-        }
+
+    if (ndev == 1 || n <= per) {
+        std::string err;
+        return device_job(0, &err);
     }
-    // chunk j of device di: upload on copy_in, kernel on the context stream, download on copy_out
-    auto upload_and_launch = [&](size_t di, size_t j) -> int {
-        Plan& pl = plans[di];
-        if (j >= pl.nchunks) return ZC_OK;
-        DevState& ds = ctx->devs[di];
-        HIP_TRY(hipSetDevice(ds.device));
-        const size_t off = j * pl.chunk, cnt = std::min(pl.chunk, pl.cnt - off);
-        void* dptr[MAX_ARGS];
-        for (int a = 0; a < nargs; a++) {
-            dptr[a] = pl.base[a] ? (char*)pl.base[a] + args[a].elt_bytes * off : nullptr;
-            if (!args[a].ptr || args[a].is_out) continue;
-            const char* src = (const char*)args[a].ptr + args[a].elt_bytes * (pl.lo + off);
-            HIP_TRY(hipMemcpyAsync(dptr[a], src, args[a].elt_bytes * cnt, hipMemcpyHostToDevice, ds.copy_in));
+    std::vector<int> rcs(ndev, ZC_OK);
+    std::vector<std::string> errs(ndev);
+    std::vector<std::thread> workers;
+    for (size_t di = 1; di < ndev; di++) workers.emplace_back([&, di] { rcs[di] = device_job(di, &errs[di]); });
+    rcs[0] = device_job(0, &errs[0]);
+    for (auto& t : workers) t.join();
+    (void)hipSetDevice(ctx->devs[0].device);
+    for (size_t di = 0; di < ndev; di++)
+        if (rcs[di]) {
+            g_last_error = errs[di];
+            return rcs[di];
         }
-        HIP_TRY(hipEventRecord(ds.ev[2 * j], ds.copy_in));
-        HIP_TRY(hipStreamWaitEvent(ds.s(), ds.ev[2 * j], 0));
-        launch(dptr, cnt, ds);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ds.ev[2 * j + 1], ds.s()));
-        return ZC_OK;
-    };
-    auto download = [&](size_t di, size_t j) -> int {
-        Plan& pl = plans[di];
-        if (j >= pl.nchunks) return ZC_OK;
-        DevState& ds = ctx->devs[di];
-        HIP_TRY(hipSetDevice(ds.device));
-        const size_t off = j * pl.chunk, cnt = std::min(pl.chunk, pl.cnt - off);
-        HIP_TRY(hipStreamWaitEvent(ds.copy_out, ds.ev[2 * j + 1], 0));
-        for (int a = 0; a < nargs; a++) {
-            if (!args[a].ptr || !args[a].is_out) continue;
-            char* dst = (char*)const_cast<void*>(args[a].ptr) + args[a].elt_bytes * (pl.lo + off);
-            HIP_TRY(hipMemcpyAsync(dst, (char*)pl.base[a] + args[a].elt_bytes * off, args[a].elt_bytes * cnt, hipMemcpyDeviceToHost, ds.copy_out));
-        }
-        return ZC_OK;
-    };
-    // Copies from/to pageable memory block the calling thread, so the issue order keeps
-    // LOOKAHEAD kernels queued on every device before the thread waits on a download.
-    constexpr size_t LOOKAHEAD = 2;
-    int rc = ZC_OK;
-    for (size_t j = 0; j < std::min(LOOKAHEAD, max_chunks) && !rc; j++)
-        for (size_t di = 0; di < ndev && !rc; di++) rc = upload_and_launch(di, j);
-    for (size_t j = 0; j < max_chunks && !rc; j++) {
-        for (size_t di = 0; di < ndev && !rc; di++) rc = download(di, j);
-        for (size_t di = 0; di < ndev && !rc; di++) rc = upload_and_launch(di, j + LOOKAHEAD);
-    }
-    for (size_t di = 0; di < ndev; di++) {
-        if (!plans[di].cnt) continue;
-        DevState& ds = ctx->devs[di];
-        HIP_TRY(hipSetDevice(ds.device));
-        HIP_TRY(hipStreamSynchronize(ds.copy_in));
-        HIP_TRY(hipStreamSynchronize(ds.s()));
-        HIP_TRY(hipStreamSynchronize(ds.copy_out));
-    }
-    return rc;
+    return ZC_OK;
 }
 
 inline Arg in_arg(const void* p, size_t b) { return Arg{p, b, false}; }
@@ -338,6 +366,43 @@ inline strict_kernel_t strict_kernel_for(size_t cnt)
 {
     return grid_for(cnt) <= SMALL_LAUNCH_BLOCKS ? zc::k_ed_scalar_mul_small : zc::k_ed_scalar_mul;
 }
+// The windowed-core kernels keep 1 KB of table scratch per lane.  A launch covers at most
+// FAST_CHUNK_LANES elements (four full rounds of three 256-thread workgroups per CU on 256 CUs, so no
+// chunk but the last ends in a partial round) and larger batches go chunk by chunk on the stream over
+// the same 768 MB of scratch.  ZC_FAST_CHUNK overrides (lanes).
+constexpr size_t FAST_CHUNK_LANES = (size_t)256 * 3 * 4 * 256;
+inline size_t fast_chunk()
+{
+    if (const char* e = getenv("ZC_FAST_CHUNK")) {
+        const long long v = atoll(e);
+        if (v >= 256 && v < (1ll << 31)) return (size_t)v / 256 * 256;
+    }
+    return FAST_CHUNK_LANES;
+}
+// Chunks alternate between the launch stream and `aux`, each with its own table scratch, so the
+// next chunk's workgroups fill the slots the previous chunk's last round leaves free (one stream alone
+// drains the chip between chunks: +4 % at 2^22).  launch(stream, table, offset, count).
+template <class L>
+int fast_chunked(DevState& D, size_t cnt, L&& launch)
+{
+    const size_t chunk = fast_chunk();
+    int rc = ensure(&D.fast, &D.fast_bytes, std::min(chunk, (size_t)grid_for(cnt) * zc::ZC_BLOCK) * 1024);
+    if (rc) return rc;
+    if (cnt <= chunk) {
+        launch(D.s(), (zc::u32*)D.fast, (size_t)0, cnt);
+        return ZC_OK;
+    }
+    rc = ensure(&D.fast2, &D.fast2_bytes, std::min(chunk, cnt - chunk + zc::ZC_BLOCK) * 1024);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(D.ev_fork, D.s()));
+    HIP_TRY(hipStreamWaitEvent(D.aux, D.ev_fork, 0));       // inputs are ready where the launch stream is now
+    size_t j = 0;
+    for (size_t off = 0; off < cnt; off += chunk, j++)
+        launch((j & 1) ? D.aux : D.s(), (zc::u32*)((j & 1) ? D.fast2 : D.fast), off, std::min(chunk, cnt - off));
+    HIP_TRY(hipEventRecord(D.ev_join, D.aux));
+    HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_join, 0));
+    return ZC_OK;
+}
 int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
 {
     REQUIRE(p); REQUIRE(k); REQUIRE(out);
@@ -393,6 +458,26 @@ struct Carver {
     }
 };
 
+// Window width: signed digits put 2^(c-1) buckets in a window; c = log2(n) - 4 keeps about 32
+// points per bucket, where the bucket reduction (~3.7 additions per bucket) stays well below the
+// bucket sums (1 addition per point and window); measured flat within 3 % for c +- 1 at 2^20, 2^21 and
+// for c = 18..21 at 2^24.  ZC_MSM_WINDOW=c overrides (tests, tuning).
+int msm_window_bits(size_t cnt)
+{
+    int c = 0;
+    while (((size_t)1 << (c + 1)) <= cnt) c++;
+    c -= 4;
+    if (c < zc::MSM_MIN_C) c = zc::MSM_MIN_C;
+    if (c > 19) c = 19;                                   // beyond: flat in time (measured to 2^24), bucket memory doubles per step
+    if (const char* e = getenv("ZC_MSM_WINDOW")) {
+        const int f = atoi(e);
+        if (f >= zc::MSM_MIN_C && f <= zc::MSM_MAX_C) c = f;
+    }
+    return c;
+}
+
+// sum_i k_i P_i of one device's shard, enqueued on D.s() without any host synchronisation;
+// *result points at the 160-byte sum in D's memory (valid until the next MSM on this device).
 int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u64** result)
 {
     if (cnt < MSM_BUCKET_MIN_N) {
@@ -407,50 +492,34 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         HIP_TRY(hipGetLastError());
         return ZC_OK;
     }
-    // window width: ~16-32 points per bucket, 4 <= c <= 16
-    int c = 0;
-    while (((size_t)1 << (c + 1)) <= cnt) c++;
-    c -= 4;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    if (const char* e = getenv("ZC_MSM_WINDOW")) {         // test hook: force the window width
-        const int f = atoi(e);
-        if (f >= 4 && f <= 16) c = f;
-    }
-    // number of windows from the longest scalar actually present (canonical scalars: 250-253 bits)
-    int maxbits = 0;
-    {
-        int rc = ensure(&D.tmp[1], &D.tmp_bytes[1], 256);
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(D.tmp[1], 0, sizeof(int), D.s()));
-        hipLaunchKernelGGL(zc::k_msm_maxbits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, (int*)D.tmp[1], cnt);
-        HIP_TRY(hipMemcpyAsync(&maxbits, D.tmp[1], sizeof(int), hipMemcpyDeviceToHost, D.s()));
-        HIP_TRY(hipStreamSynchronize(D.s()));
-    }
-    if (maxbits == 0) {                                   // all scalars zero: the sum is the identity
-        static const uint64_t ident[20] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int rc = ensure(&D.tmp[0], &D.tmp_bytes[0], 256);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(D.tmp[0], ident, sizeof ident, hipMemcpyHostToDevice, D.s()));
-        HIP_TRY(hipStreamSynchronize(D.s()));
-        *result = (const u64*)D.tmp[0];
-        return ZC_OK;
-    }
-    const int W = (maxbits + c - 1) / c;
+    if (cnt > 0x7FFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 31-bit point indices");
+    const int c = msm_window_bits(cnt);
+    const int W = (zc::MSM_SCALAR_BITS + c - 1) / c;      // any 260-bit pattern + the recoding carry
     const size_t m = cnt * (size_t)W;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
-    const size_t nb = (size_t)W << c;                     // buckets
+    const size_t nb = (size_t)W << (c - 1);               // buckets (digit magnitudes 1 .. 2^(c-1) per window)
     const size_t nseg = nb / zc::MSM_SEG;
-    int keybits = c;
-    while ((1 << (keybits - c)) < W) keybits++;
+    int keybits = c - 1;
+    while (((size_t)1 << keybits) <= nb) keybits++;       // the sentinel key nb must sort last
 
+    // run length of the segmented reduction: 32 entries per lane, fewer when the list is short
+    // (keep >= 64 K lanes busy); ZC_MSM_RUN overrides
+    // Longer runs leave fewer edges (2 per run) for the deeper levels; 2^19 lanes keep the chip full.
+    int T = (int)std::min<size_t>(128, std::max<size_t>(8, m >> 19));
+    int TE = 16;                                          // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
+    if (const char* e = getenv("ZC_MSM_RUN")) {
+        const int f = atoi(e);
+        if (f >= 4 && f <= 4096) T = f;                   // T >= 4: every level shortens the list (2 ceil(len / T) < len)
+    }
+    if (const char* e = getenv("ZC_MSM_RUN_EDGES")) {
+        const int f = atoi(e);
+        if (f >= 4 && f <= 4096) TE = f & ~1;
+    }
+    const size_t nl0 = (m + T - 1) / T;                   // lanes (= runs) of level 0
     size_t sort_tmp = 0;
     {
         rocprim::double_buffer<zc::u32> kq(nullptr, nullptr), vq(nullptr, nullptr);
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tmp, kq, vq, m, 0, (unsigned)keybits, D.s()));
-        size_t t2 = 0;
-        HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, t2, kq, vq, nb, 0, 32, D.s()));
-        if (t2 > sort_tmp) sort_tmp = t2;
     }
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
@@ -459,14 +528,10 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         zc::u32* vals0 = cv.take<zc::u32>(m);
         zc::u32* vals1 = cv.take<zc::u32>(m);
         char* tmp = cv.take<char>(sort_tmp);
-        zc::u32* start = cv.take<zc::u32>(nb);
-        zc::u32* end = cv.take<zc::u32>(nb);
-        zc::u32* bcnt0 = cv.take<zc::u32>(nb);
-        zc::u32* bcnt1 = cv.take<zc::u32>(nb);
-        zc::u32* bid0 = cv.take<zc::u32>(nb);
-        zc::u32* bid1 = cv.take<zc::u32>(nb);
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
-        u64* buckets = cv.take<u64>(nb * 20);
+        zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
+        zc::u32* ekeys[2] = {cv.take<zc::u32>(2 * nl0), cv.take<zc::u32>(2 * nl0)};       // edge lists, ping-pong
+        zc::u32* erecs[2] = {cv.take<zc::u32>(2 * nl0 * zc::MSM_RAW_WORDS), cv.take<zc::u32>(2 * nl0 * zc::MSM_RAW_WORDS)};
         u64* seg_sum = cv.take<u64>(nseg * 20);
         u64* seg_acc = cv.take<u64>(nseg * 20);
         u64* seg_k = cv.take<u64>(nseg * 5);
@@ -480,18 +545,35 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         rocprim::double_buffer<zc::u32> kb(keys0, keys1), vb(vals0, vals1);
         size_t st = sort_tmp;
         HIP_TRY(rocprim::radix_sort_pairs(tmp, st, kb, vb, m, 0, (unsigned)keybits, D.s()));
-        HIP_TRY(hipMemsetAsync(start, 0, nb * sizeof(zc::u32), D.s()));
-        HIP_TRY(hipMemsetAsync(end, 0, nb * sizeof(zc::u32), D.s()));
-        hipLaunchKernelGGL(zc::k_msm_bounds, dim3(grid_for(m)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)kb.current(), start, end, m);
         hipLaunchKernelGGL(zc::k_msm_prepare, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
-        hipLaunchKernelGGL(zc::k_msm_counts, dim3(grid_for(nb)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)start, (const zc::u32*)end, bcnt0, bid0, nb, c);
-        rocprim::double_buffer<zc::u32> cb(bcnt0, bcnt1), ib(bid0, bid1);
-        st = sort_tmp;
-        HIP_TRY(rocprim::radix_sort_pairs_desc(tmp, st, cb, ib, nb, 0, 32, D.s()));
-        hipLaunchKernelGGL(zc::k_msm_accumulate, dim3(grid_for(nb)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)cached, (const zc::u32*)vb.current(),
-                           (const zc::u32*)start, (const zc::u32*)end, (const zc::u32*)ib.current(), buckets, nb, c);
-        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)buckets, seg_sum, seg_acc, seg_k, nseg, c);
-        // seg_acc <- (lo - 1) * seg_acc ; seg_sum <- seg_sum + seg_acc
+        HIP_TRY(hipMemsetAsync(buckets, 0, nb * zc::MSM_RAW_WORDS * sizeof(zc::u32), D.s()));   // all-zero record = empty bucket
+        // bucket sums: segmented reduction of the sorted list in runs of T, level by level
+        {
+            const zc::u32* lk = kb.current();
+            const zc::u32* lr = nullptr;
+            size_t len = m;
+            for (int level = 0;; level++) {
+                // level 0: runs [jT, (j+1)T); deeper: runs shifted by one entry, [jT+1, (j+1)T+1), run 0 one longer
+                const size_t t = level ? (size_t)TE : (size_t)T;
+                const size_t nl = level ? (len <= t + 1 ? 1 : (len - 1 + t - 1) / t) : (len + t - 1) / t;
+                zc::u32* nk = ekeys[level & 1];
+                zc::u32* nr = erecs[level & 1];
+                if (nl > 1) HIP_TRY(hipMemsetAsync(nk, 0xFF, 2 * nl * sizeof(zc::u32), D.s()));
+                if (level == 0)
+                    hipLaunchKernelGGL(zc::k_msm_runs, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, (const zc::u32*)vb.current(), (const zc::u32*)cached,
+                                       (zc::u32)len, (zc::u32)t, (zc::u32)nb, buckets, nk, nr);
+                else
+                    hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
+                                       buckets, nk, nr);
+                if (nl <= 1) break;                        // one lane saw the whole list: nothing is left open
+                if (level > 40) return fail(ZC_ERR_HIP, "zc_msm: segmented reduction did not converge");
+                lk = nk;
+                lr = nr;
+                len = 2 * nl;
+            }
+        }
+        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)buckets, seg_sum, seg_acc, seg_k, nseg, c);
+        // seg_acc <- (first mod 2^(c-1)) * seg_acc ; seg_sum <- seg_sum + seg_acc
         hipLaunchKernelGGL(strict_kernel_for(nseg), dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
                            seg_acc, (const zc::u32*)nullptr, nseg);
         hipLaunchKernelGGL(zc::k_ed_add, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_sum, (const u64*)seg_acc, seg_sum, nseg);
@@ -511,6 +593,73 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     }
     return ZC_OK;
 }
+
+// ---------------------------------------------------------------- RCCL (opened on demand)
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.handle) return ZC_OK;
+    // an RCCL already mapped by the host application (PyTorch ships one) is shared, not duplicated
+    const char* names[] = {getenv("ZC_RCCL_PATH"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names)
+        if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* nm : names)
+        if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(ZC_ERR_HIP, "librccl.so not found (set ZC_RCCL_PATH)");
+    RcclApi api;
+    api.handle = h;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString)
+        return fail(ZC_ERR_HIP, "librccl.so lacks an expected symbol");
+    g_rccl = api;
+    return ZC_OK;
+}
+int rccl_fail(const char* what, ncclResult_t r)
+{
+    g_last_error = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+    return ZC_ERR_HIP;
+}
+#define RCCL_TRY(expr)                                         \
+    do {                                                       \
+        ncclResult_t r_ = (expr);                              \
+        if (r_ != ncclSuccess) return rccl_fail(#expr, r_);    \
+    } while (0)
+
+DevState* dev_state_of(zc_ctx* ctx, int device)
+{
+    for (auto& d : ctx->devs)
+        if (d.device == device) return &d;
+    return nullptr;
+}
+
+// One device's shard of an MSM, inputs host (staged) or device (in place); the 160-byte sum stays
+// in device memory (*result), everything enqueued on ds.s().
+int msm_shard(DevState& ds, const uint64_t* points, const uint64_t* scalars, size_t cnt, bool on_device, const u64** result)
+{
+    HIP_TRY(hipSetDevice(ds.device));
+    const u64 *dP = points, *dK = scalars;
+    if (!on_device) {
+        int rc = ensure(&ds.scratch[0], &ds.scratch_bytes[0], cnt * 160);
+        if (rc) return rc;
+        rc = ensure(&ds.scratch[1], &ds.scratch_bytes[1], cnt * 40);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ds.scratch[0], points, cnt * 160, hipMemcpyHostToDevice, ds.s()));
+        HIP_TRY(hipMemcpyAsync(ds.scratch[1], scalars, cnt * 40, hipMemcpyHostToDevice, ds.s()));
+        dP = (const u64*)ds.scratch[0];
+        dK = (const u64*)ds.scratch[1];
+    }
+    return msm_on_device(ds, dP, dK, cnt, result);
+}
+
+const uint64_t IDENT_POINT[20] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 }  // namespace
 
@@ -552,9 +701,14 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         DevState ds;
         ds.device = id;
         hipError_t e = hipSetDevice(id);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&ds.cus, hipDeviceAttributeMultiprocessorCount, id);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_in, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_out, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_order, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.aux, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming);
         if (e != hipSuccess) {
             delete ctx;
             return fail(ZC_ERR_HIP, "stream creation", e);
@@ -569,9 +723,12 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
 int zc_ctx_destroy(zc_ctx* ctx)
 {
     if (!ctx) return ZC_OK;
+    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
     for (auto& ds : ctx->devs) {
         (void)hipSetDevice(ds.device);
         (void)hipStreamSynchronize(ds.s());
+        if (ds.part) (void)hipFree(ds.part);
+        if (ds.ev_order) (void)hipEventDestroy(ds.ev_order);
         for (int a = 0; a < MAX_ARGS; a++)
             if (ds.scratch[a]) (void)hipFree(ds.scratch[a]);
         for (int a = 0; a < 2; a++)
@@ -579,6 +736,10 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.bal) (void)hipFree(ds.bal);
         if (ds.msm) (void)hipFree(ds.msm);
         if (ds.fast) (void)hipFree(ds.fast);
+        if (ds.fast2) (void)hipFree(ds.fast2);
+        if (ds.aux) { (void)hipStreamSynchronize(ds.aux); (void)hipStreamDestroy(ds.aux); }
+        if (ds.ev_fork) (void)hipEventDestroy(ds.ev_fork);
+        if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
         if (ds.base_table) (void)hipFree(ds.base_table);
         for (hipEvent_t e : ds.ev) (void)hipEventDestroy(e);
         if (ds.copy_in) (void)hipStreamDestroy(ds.copy_in);
@@ -589,12 +750,38 @@ int zc_ctx_destroy(zc_ctx* ctx)
     return ZC_OK;
 }
 
-int zc_ctx_set_stream(zc_ctx* ctx, void* hip_stream, int external)
+// Switching the launch stream of a device slot: everything already enqueued on the old stream
+// (including the producers of shared scratch: window tables, MSM workspace, the basepoint table)
+// is ordered before later work on the new one with an event, without a host synchronisation.
+int zc_ctx_set_stream_dev(zc_ctx* ctx, int slot, void* hip_stream, int external)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    if (slot < 0 || (size_t)slot >= ctx->devs.size()) return fail(ZC_ERR_BAD_ARG, "device slot out of range");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->devs[0].borrowed = external ? (hipStream_t)hip_stream : nullptr;
-    ctx->devs[0].use_borrowed = external != 0;
+    DevState& ds = ctx->devs[slot];
+    hipStream_t next = external ? (hipStream_t)hip_stream : ds.stream;
+    if (ds.s() == next && ds.use_borrowed == (external != 0)) return ZC_OK;
+    HIP_TRY(hipSetDevice(ds.device));
+    HIP_TRY(hipEventRecord(ds.ev_order, ds.s()));
+    HIP_TRY(hipStreamWaitEvent(next, ds.ev_order, 0));
+    ds.borrowed = external ? (hipStream_t)hip_stream : nullptr;
+    ds.use_borrowed = external != 0;
+    return ZC_OK;
+}
+int zc_ctx_set_stream(zc_ctx* ctx, void* hip_stream, int external) { return zc_ctx_set_stream_dev(ctx, 0, hip_stream, external); }
+
+// Pin a caller-owned host buffer (hipHostRegister): copies from / to it are truly asynchronous
+// and skip the runtime's bounce buffers.  Worth it for buffers reused across calls.
+int zc_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(ZC_ERR_BAD_ARG, "zc_host_register: null buffer");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return ZC_OK;
+}
+int zc_host_unregister(void* ptr)
+{
+    if (!ptr) return fail(ZC_ERR_BAD_ARG, "zc_host_unregister: null buffer");
+    HIP_TRY(hipHostUnregister(ptr));
     return ZC_OK;
 }
 
@@ -721,10 +908,10 @@ int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t
         Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
         int inner = ZC_OK;
         int rc = run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-            const size_t lanes = (size_t)grid_for(cnt) * zc::ZC_BLOCK;
-            if ((inner = ensure(&D.fast, &D.fast_bytes, lanes * 1024)) != ZC_OK) return;
-            hipLaunchKernelGGL(zc::k_ed_scalar_mul_fast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
-                               (const u64*)d[1], (size_t)5, (u64*)d[2], (zc::u32*)D.fast, cnt);
+            inner = fast_chunked(D, cnt, [&](hipStream_t st, zc::u32* table, size_t off, size_t c) {
+                hipLaunchKernelGGL(zc::k_ed_scalar_mul_fast, dim3(grid_for(c)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)d[0] + 20 * off,
+                                   (const u64*)d[1] + 5 * off, (zc::u32)5, (u64*)d[2] + 20 * off, table, (zc::u32)c);
+            });
         }, true);
         return rc ? rc : inner;
     }
@@ -822,9 +1009,10 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
             hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
             return;
         }
-        const size_t lanes = (size_t)grid_for(cnt) * zc::ZC_BLOCK;
-        if ((inner = ensure(&D.fast, &D.fast_bytes, lanes * 1024)) != ZC_OK) return;
-        hipLaunchKernelGGL(zc::k_ris_roundtrip_mul_fast, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], (zc::u32*)D.fast, cnt);
+        inner = fast_chunked(D, cnt, [&](hipStream_t st, zc::u32* table, size_t off, size_t c) {
+            hipLaunchKernelGGL(zc::k_ris_roundtrip_mul_fast, dim3(grid_for(c)), dim3(zc::ZC_BLOCK), 0, st, (const uint8_t*)d[0] + 32 * off,
+                               (const u64*)d[1] + 5 * off, (uint8_t*)d[2] + 32 * off, d[3] ? (uint8_t*)d[3] + off : (uint8_t*)nullptr, table, (zc::u32)c);
+        });
     }, true);
     return rc ? rc : inner;
 }
@@ -910,87 +1098,250 @@ int zc_ris_mul_base_compress(zc_ctx* ctx, const uint64_t* k, uint8_t* out32, siz
     return rc ? rc : inner;
 }
 
-// ---- MSM: sum_i k_i * P_i (not in the reference).  Per GPU: bucket method (zc_msm.cuh) for
-// shards of >= MSM_BUCKET_MIN_N pairs, otherwise batched scalar-mul + pairwise folds.  The
-// per-device partial points are folded in device order on the first device.
-int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out_point)
+// ---- MSM: sum_i k_i * P_i (not in the reference; specified as the reference's own
+// sum of `&P_i * &k_i`, src/edwards.rs:547-561 + :465-489).  Per GPU: bucket method (zc_msm.cuh)
+// for shards of >= MSM_BUCKET_MIN_N pairs, otherwise batched scalar-mul + pairwise folds.
+// The exchange step lives here: per-device partial sums are gathered INTO DEVICE MEMORY
+// (hipMemcpyPeerAsync inside one process, ncclAllGather between processes) and folded in
+// device / rank order by ONE kernel (k_ed_fold_ordered), so every rank ends with identical limbs.
+
+// partial sums of all device slots -> slot 0's `part` buffer, folded there; result at part[nparts]
+static int gather_and_fold(zc_ctx* ctx, const std::vector<DevState*>& used, const std::vector<const u64*>& partial_ptr, const u64** result)
 {
-    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
-    REQUIRE(points); REQUIRE(scalars); REQUIRE(out_point);
-    static const uint64_t ident[20] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (n == 0) {
-        memcpy(out_point, ident, sizeof ident);
+    DevState* d0 = used[0];
+    const size_t np = used.size();
+    if (np == 1) {
+        *result = partial_ptr[0];
         return ZC_OK;
     }
+    HIP_TRY(hipSetDevice(d0->device));
+    int rc = ensure(&d0->part, &d0->part_bytes, (np + 1) * 160);
+    if (rc) return rc;
+    u64* part = (u64*)d0->part;
+    for (size_t ui = 0; ui < np; ui++) {
+        DevState* ds = used[ui];
+        HIP_TRY(hipSetDevice(ds->device));
+        if (ds->device == d0->device) HIP_TRY(hipMemcpyAsync(part + 20 * ui, partial_ptr[ui], 160, hipMemcpyDeviceToDevice, ds->s()));
+        else HIP_TRY(hipMemcpyPeerAsync(part + 20 * ui, d0->device, partial_ptr[ui], ds->device, 160, ds->s()));
+        if (ds != d0) {
+            HIP_TRY(hipEventRecord(ds->ev_order, ds->s()));
+            HIP_TRY(hipStreamWaitEvent(d0->s(), ds->ev_order, 0));
+        }
+    }
+    HIP_TRY(hipSetDevice(d0->device));
+    hipLaunchKernelGGL(zc::k_ed_fold_ordered, dim3(1), dim3(64), 0, d0->s(), (const u64*)part, np, (const u64*)nullptr, part + 20 * np);
+    HIP_TRY(hipGetLastError());
+    *result = part + 20 * np;
+    return ZC_OK;
+}
+
+// local part of an MSM over every device slot of the context (host inputs: contiguous shards, one
+// worker thread per slot; device inputs: the owning slot); *result in device memory of *owner
+static int msm_local(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, DevState** owner, const u64** result)
+{
     Residency rp, rk;
     int dp = -1, dk = -1;
     residency_of(points, &rp, &dp);
     residency_of(scalars, &rk, &dk);
     if (rp != rk || (rp == RES_DEVICE && dp != dk)) return fail(ZC_ERR_MIXED_MEM, "points/scalars residency differs");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-
-    const size_t ndev = (rp == RES_DEVICE) ? 1 : ctx->devs.size();
-    const size_t per = (n + ndev - 1) / ndev;
     std::vector<DevState*> used;
     std::vector<const u64*> partial_ptr;
-    for (size_t di = 0; di < ndev; di++) {
-        const size_t lo = di * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        const size_t cnt = hi - lo;
-        DevState* ds = nullptr;
-        if (rp == RES_DEVICE) {
-            for (auto& x : ctx->devs)
-                if (x.device == dp) ds = &x;
-            if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
-        } else {
-            ds = &ctx->devs[di];
-        }
-        HIP_TRY(hipSetDevice(ds->device));
-        const u64 *dP, *dK;
-        if (rp == RES_DEVICE) {
-            dP = points;
-            dK = scalars;
-        } else {
-            int rc = ensure(&ds->scratch[0], &ds->scratch_bytes[0], cnt * 160);
-            if (rc) return rc;
-            rc = ensure(&ds->scratch[1], &ds->scratch_bytes[1], cnt * 40);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(ds->scratch[0], points + 20 * lo, cnt * 160, hipMemcpyHostToDevice, ds->s()));
-            HIP_TRY(hipMemcpyAsync(ds->scratch[1], scalars + 5 * lo, cnt * 40, hipMemcpyHostToDevice, ds->s()));
-            dP = (const u64*)ds->scratch[0];
-            dK = (const u64*)ds->scratch[1];
-        }
+    if (rp == RES_DEVICE) {
+        DevState* ds = dev_state_of(ctx, dp);
+        if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
         const u64* part = nullptr;
-        int rc = msm_on_device(*ds, dP, dK, cnt, &part);
+        int rc = msm_shard(*ds, points, scalars, n, true, &part);
         if (rc) return rc;
-        used.push_back(ds);
-        partial_ptr.push_back(part);
+        *owner = ds;
+        *result = part;
+        return ZC_OK;
     }
-    std::vector<uint64_t> partials(used.size() * 20);
-    for (size_t ui = 0; ui < used.size(); ui++) {
-        HIP_TRY(hipSetDevice(used[ui]->device));
-        HIP_TRY(hipMemcpyAsync(partials.data() + 20 * ui, partial_ptr[ui], 160, hipMemcpyDeviceToHost, used[ui]->s()));
+    const size_t ndev = ctx->devs.size();
+    const size_t per = (n + ndev - 1) / ndev;
+    size_t nshards = 0;
+    while (nshards < ndev && nshards * per < n) nshards++;
+    std::vector<int> rcs(nshards, ZC_OK);
+    std::vector<std::string> errs(nshards);
+    partial_ptr.assign(nshards, nullptr);
+    auto job = [&](size_t di) {
+        const size_t lo = di * per, hi = std::min(n, lo + per);
+        rcs[di] = msm_shard(ctx->devs[di], points + 20 * lo, scalars + 5 * lo, hi - lo, false, &partial_ptr[di]);
+        if (rcs[di]) errs[di] = g_last_error;
+    };
+    std::vector<std::thread> workers;                       // pageable uploads block their thread: one per device
+    for (size_t di = 1; di < nshards; di++) workers.emplace_back(job, di);
+    job(0);
+    for (auto& t : workers) t.join();
+    for (size_t di = 0; di < nshards; di++) {
+        if (rcs[di]) {
+            g_last_error = errs[di];
+            return rcs[di];
+        }
+        used.push_back(&ctx->devs[di]);
     }
-    for (DevState* ds : used) {
-        HIP_TRY(hipSetDevice(ds->device));
-        HIP_TRY(hipStreamSynchronize(ds->s()));
+    *owner = used[0];
+    return gather_and_fold(ctx, used, partial_ptr, result);
+}
+
+int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out_point)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(points); REQUIRE(scalars); REQUIRE(out_point);
+    if (n == 0) {
+        memcpy(out_point, IDENT_POINT, sizeof IDENT_POINT);
+        return ZC_OK;
     }
-    // fold the per-device partials in device order on the first device
-    size_t cnt = used.size();
-    if (cnt > 1) {
-        DevState* ds = used[0];
-        HIP_TRY(hipSetDevice(ds->device));
-        int rc = ensure(&ds->tmp[0], &ds->tmp_bytes[0], cnt * 160);
-        if (rc) return rc;
-        rc = ensure(&ds->tmp[1], &ds->tmp_bytes[1], cnt * 160);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ds->tmp[0], partials.data(), cnt * 160, hipMemcpyHostToDevice, ds->s()));
-        const u64* res = fold_all(*ds, (u64*)ds->tmp[0], (u64*)ds->tmp[1], cnt);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DevState* owner = nullptr;
+    const u64* res = nullptr;
+    int rc = msm_local(ctx, points, scalars, n, &owner, &res);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(owner->device));
+    HIP_TRY(hipMemcpyAsync(out_point, res, 160, hipMemcpyDeviceToHost, owner->s()));
+    HIP_TRY(hipStreamSynchronize(owner->s()));
+    return ZC_OK;
+}
+
+// The same with the sum left in DEVICE memory (out_dev_point: 160 bytes on the device that owns
+// the inputs, or on device slot 0 for host inputs); asynchronous on the context stream.
+int zc_msm_partial(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out_dev_point)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(out_dev_point);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    Residency ro;
+    int dvo = -1;
+    residency_of(out_dev_point, &ro, &dvo);
+    if (ro != RES_DEVICE) return fail(ZC_ERR_MIXED_MEM, "zc_msm_partial: out_dev_point must be device memory");
+    DevState* od = dev_state_of(ctx, dvo);
+    if (!od) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+    if (n == 0) {
+        HIP_TRY(hipSetDevice(od->device));
+        HIP_TRY(hipMemcpyAsync(out_dev_point, IDENT_POINT, 160, hipMemcpyHostToDevice, od->s()));
+        HIP_TRY(hipStreamSynchronize(od->s()));           // the source is host constant memory
+        return ZC_OK;
+    }
+    REQUIRE(points); REQUIRE(scalars);
+    DevState* owner = nullptr;
+    const u64* res = nullptr;
+    int rc = msm_local(ctx, points, scalars, n, &owner, &res);
+    if (rc) return rc;
+    if (owner != od) return fail(ZC_ERR_MIXED_MEM, "zc_msm_partial: output lives on another device than the sum");
+    HIP_TRY(hipSetDevice(owner->device));
+    HIP_TRY(hipMemcpyAsync(out_dev_point, res, 160, hipMemcpyDeviceToDevice, owner->s()));
+    return ZC_OK;
+}
+
+// ((p_0 + p_1) + p_2) + ... + p_(count-1), unified addition (src/edwards.rs:465-489), ONE launch;
+// host or device pointers as everywhere.  The exchange step of a sharded MSM after an all-gather.
+int zc_ed_fold_ordered(zc_ctx* ctx, const uint64_t* parts, size_t count, uint64_t* out)
+{
+    REQUIRE(parts); REQUIRE(out);
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    if (count == 0) return fail(ZC_ERR_BAD_ARG, "zc_ed_fold_ordered: empty list");
+    Residency rp, ro;
+    int dp = -1, dvo = -1;
+    residency_of(parts, &rp, &dp);
+    residency_of(out, &ro, &dvo);
+    if (rp != ro || (rp == RES_DEVICE && dp != dvo)) return fail(ZC_ERR_MIXED_MEM, "host and device buffers mixed in one call");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DevState* ds = rp == RES_DEVICE ? dev_state_of(ctx, dp) : &ctx->devs[0];
+    if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+    HIP_TRY(hipSetDevice(ds->device));
+    if (rp == RES_DEVICE) {
+        hipLaunchKernelGGL(zc::k_ed_fold_ordered, dim3(1), dim3(64), 0, ds->s(), (const u64*)parts, count, (const u64*)nullptr, (u64*)out);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(partials.data(), res, 160, hipMemcpyDeviceToHost, ds->s()));
-        HIP_TRY(hipStreamSynchronize(ds->s()));
+        return ZC_OK;
     }
-    memcpy(out_point, partials.data(), 160);
+    int rc = ensure(&ds->part, &ds->part_bytes, (count + 1) * 160);
+    if (rc) return rc;
+    u64* part = (u64*)ds->part;
+    HIP_TRY(hipMemcpyAsync(part, parts, count * 160, hipMemcpyHostToDevice, ds->s()));
+    hipLaunchKernelGGL(zc::k_ed_fold_ordered, dim3(1), dim3(64), 0, ds->s(), (const u64*)part, count, (const u64*)nullptr, part + 20 * count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, part + 20 * count, 160, hipMemcpyDeviceToHost, ds->s()));
+    HIP_TRY(hipStreamSynchronize(ds->s()));
+    return ZC_OK;
+}
+
+// ---- one process per GPU: RCCL communicator owned by the context ------------------------------
+int zc_comm_unique_id(uint8_t* id_out128)
+{
+    REQUIRE(id_out128);
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id_out128, &id, sizeof id);
+    return ZC_OK;
+}
+int zc_comm_init(zc_ctx* ctx, const uint8_t* id128, int rank, int world)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(id128);
+    if (world < 1 || rank < 0 || rank >= world) return fail(ZC_ERR_BAD_ARG, "zc_comm_init: bad rank / world size");
+    int rc = rccl_load();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->comm) return fail(ZC_ERR_BAD_ARG, "zc_comm_init: the context already has a communicator");
+    HIP_TRY(hipSetDevice(ctx->devs[0].device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    RCCL_TRY(g_rccl.CommInitRank(&ctx->comm, world, id, rank));
+    ctx->rank = rank;
+    ctx->world = world;
+    return ZC_OK;
+}
+int zc_comm_destroy(zc_ctx* ctx)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->comm) {
+        (void)zc_ctx_synchronize(ctx);
+        RCCL_TRY(g_rccl.CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+        ctx->world = 1;
+        ctx->rank = 0;
+    }
+    return ZC_OK;
+}
+
+// BASELINE configs[4]: this rank's shard of a global MSM.  Local bucket method -> ncclAllGather of
+// the 160-byte partial sums over xGMI (20 x ncclUint64 per rank, on the context stream) -> ordered
+// fold in one kernel -> every rank returns the same point (identical limbs).  Point addition is not
+// an ncclRedOp_t, hence all-gather + fold rather than ncclAllReduce.
+int zc_msm_sharded(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n_local, uint64_t* out_point)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(out_point);
+    if (!ctx->comm) return fail(ZC_ERR_BAD_ARG, "zc_msm_sharded: call zc_comm_init first");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DevState* d0 = &ctx->devs[0];
+    const size_t world = (size_t)ctx->world;
+    HIP_TRY(hipSetDevice(d0->device));
+    const size_t front = ctx->devs.size() + 1;               // gather_and_fold's region (multi-slot host inputs)
+    int rc = ensure(&d0->part, &d0->part_bytes, (front + world + 2) * 160);
+    if (rc) return rc;
+    u64* gathered = (u64*)d0->part + 20 * front;
+    u64* mine = gathered + 20 * world;                       // mine, then the folded result
+    if (n_local == 0) {
+        HIP_TRY(hipMemcpyAsync(mine, IDENT_POINT, 160, hipMemcpyHostToDevice, d0->s()));
+    } else {
+        REQUIRE(points); REQUIRE(scalars);
+        DevState* owner = nullptr;
+        const u64* res = nullptr;
+        rc = msm_local(ctx, points, scalars, n_local, &owner, &res);
+        if (rc) return rc;
+        if (owner != d0) return fail(ZC_ERR_MIXED_MEM, "zc_msm_sharded: inputs must live on device slot 0 (or on the host)");
+        HIP_TRY(hipSetDevice(d0->device));
+        HIP_TRY(hipMemcpyAsync(mine, res, 160, hipMemcpyDeviceToDevice, d0->s()));
+    }
+    RCCL_TRY(g_rccl.AllGather(mine, gathered, 20, ncclUint64, ctx->comm, d0->s()));
+    hipLaunchKernelGGL(zc::k_ed_fold_ordered, dim3(1), dim3(64), 0, d0->s(), (const u64*)gathered, world, (const u64*)nullptr, mine + 20);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_point, mine + 20, 160, hipMemcpyDeviceToHost, d0->s()));
+    HIP_TRY(hipStreamSynchronize(d0->s()));
     return ZC_OK;
 }
 

@@ -31,6 +31,8 @@ class Engine:
     def __init__(self, devices=None):
         self.lib = _lib.load()
         self.ctx = C.c_void_p()
+        self._pinned_stream = False      # set_stream() was called: keep that stream
+        self._last_torch_stream = None
         if devices:
             arr = (C.c_int * len(devices))(*devices)
             rc = self.lib.zc_ctx_create(arr, len(devices), C.byref(self.ctx))
@@ -53,19 +55,38 @@ class Engine:
         """Launch on the caller's HIP stream (handle 0 = the HIP null stream, which is what
         torch.cuda.current_stream().cuda_stream is by default)."""
         _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(stream_handle), 1), "zc_ctx_set_stream")
+        self._pinned_stream = True
 
     def use_own_stream(self):
+        """Back to the default: host batches run on the context's own stream; calls on torch CUDA
+        tensors follow torch's current stream of that device (see _follow_torch_stream)."""
         _lib.check(self.lib.zc_ctx_set_stream(self.ctx, None, 0), "zc_ctx_set_stream")
+        self._pinned_stream = False
+        self._last_torch_stream = None
+
+    def _follow_torch_stream(self, t):
+        """Device tensors are produced and consumed on torch's streams and their memory belongs to
+        torch's caching allocator, so unless the caller pinned a stream with set_stream() every
+        call on torch tensors is enqueued on torch.cuda.current_stream(device): ordered after the
+        work that produced the inputs, and outputs allocated with torch.empty are safe to use from
+        that stream.  (The library orders a stream switch with an event, no host sync.)"""
+        if self._pinned_stream:
+            return
+        import torch
+        h = torch.cuda.current_stream(t.device).cuda_stream
+        if h != self._last_torch_stream:
+            _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(h), 1), "zc_ctx_set_stream")
+            self._last_torch_stream = h
 
     def synchronize(self):
         _lib.check(self.lib.zc_ctx_synchronize(self.ctx), "zc_ctx_synchronize")
 
     # ------------------------------------------------------------------ helpers
-    @staticmethod
-    def _prep(x, width, dtype):
+    def _prep(self, x, width, dtype):
         if _is_torch(x):
             assert x.is_contiguous() and x.shape[-1] == width, (x.shape, width)
             assert x.element_size() == np.dtype(dtype).itemsize
+            self._follow_torch_stream(x)
             return x, x.data_ptr(), x.shape[0]
         a = np.ascontiguousarray(x, dtype=dtype)
         assert a.ndim == 2 and a.shape[1] == width, (a.shape, width)
@@ -329,3 +350,59 @@ class Engine:
         out = np.empty((1, 20), dtype=np.uint64)
         self._call("zc_msm", pp, pk, n, out.ctypes.data)
         return out
+
+    # ---- the exchange step of a sharded MSM (BASELINE configs[4])
+    def msm_partial(self, points, scalars, out=None):
+        """This device's sum left in device memory: a (1, 20) int64 torch CUDA tensor (asynchronous)."""
+        import torch
+        points, pp, n = self._prep(points, 20, np.uint64)
+        scalars, pk, _ = self._prep(scalars, 5, np.uint64)
+        if out is None:
+            dev = points.device if _is_torch(points) else torch.device("cuda", torch.cuda.current_device())
+            out = torch.empty((1, 20), dtype=torch.int64, device=dev)
+            self._follow_torch_stream(out)
+        self._call("zc_msm_partial", pp, pk, n, out.data_ptr())
+        return out
+
+    def ed_fold_ordered(self, parts):
+        """((p_0 + p_1) + p_2) + ... in index order, one kernel launch; (count, 20) -> (1, 20)."""
+        parts, pp, n = self._prep(parts, 20, np.uint64)
+        out, po = self._alloc(parts, 1, 20, np.uint64)
+        self._call("zc_ed_fold_ordered", pp, n, po)
+        return out
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().zc_comm_unique_id(buf), "zc_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._call("zc_comm_init", buf, rank, world)
+
+    def comm_destroy(self):
+        self._call("zc_comm_destroy")
+
+    def msm_sharded(self, points, scalars):
+        """This rank's shard of a global MSM through the library's own RCCL communicator
+        (comm_init first): local bucket method, ncclAllGather of the 160-byte partial sums,
+        ordered fold on the device.  Returns the global sum as a (1, 20) numpy array."""
+        points, pp, n = self._prep(points, 20, np.uint64)
+        scalars, pk, _ = self._prep(scalars, 5, np.uint64)
+        out = np.empty((1, 20), dtype=np.uint64)
+        self._call("zc_msm_sharded", pp, pk, n, out.ctypes.data)
+        return out
+
+    def set_stream_dev(self, slot, stream_handle):
+        self._call("zc_ctx_set_stream_dev", slot, C.c_void_p(stream_handle), 1)
+        self._pinned_stream = True
+
+    @staticmethod
+    def host_register(arr: np.ndarray):
+        _lib.check(_lib.load().zc_host_register(arr.ctypes.data, arr.nbytes), "zc_host_register")
+
+    @staticmethod
+    def host_unregister(arr: np.ndarray):
+        _lib.check(_lib.load().zc_host_unregister(arr.ctypes.data), "zc_host_unregister")

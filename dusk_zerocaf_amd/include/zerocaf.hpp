@@ -45,6 +45,19 @@ public:
     static void set_stream(void* hip_stream) { check(zc_ctx_set_stream(ctx(), hip_stream, 1), "zc_ctx_set_stream"); }
     static void use_own_stream() { check(zc_ctx_set_stream(ctx(), nullptr, 0), "zc_ctx_set_stream"); }
     static void synchronize() { check(zc_ctx_synchronize(ctx()), "zc_ctx_synchronize"); }
+    static void set_stream_dev(int slot, void* hip_stream) { check(zc_ctx_set_stream_dev(ctx(), slot, hip_stream, 1), "zc_ctx_set_stream_dev"); }
+    // pin a long-lived host buffer: host batches from it copy asynchronously
+    static void host_register(void* p, size_t bytes) { check(zc_host_register(p, bytes), "zc_host_register"); }
+    static void host_unregister(void* p) { check(zc_host_unregister(p), "zc_host_unregister"); }
+    // one process per GPU: RCCL communicator for the MSM exchange (rank 0 makes the id, every rank joins)
+    static std::array<uint8_t, 128> comm_unique_id()
+    {
+        std::array<uint8_t, 128> id{};
+        check(zc_comm_unique_id(id.data()), "zc_comm_unique_id");
+        return id;
+    }
+    static void comm_init(const std::array<uint8_t, 128>& id, int rank, int world) { check(zc_comm_init(ctx(), id.data(), rank, world), "zc_comm_init"); }
+    static void comm_destroy() { check(zc_comm_destroy(ctx()), "zc_comm_destroy"); }
 
 private:
     Backend() { check(zc_ctx_create(nullptr, 0, &ctx_), "zc_ctx_create"); }
@@ -490,6 +503,32 @@ inline EdwardsPoint msm(const std::vector<EdwardsPoint>& ps, const std::vector<S
     uint64_t o[20];
     Backend::check(zc_msm(Backend::ctx(), p.data(), k.data(), ps.size(), o), "zc_msm");
     return EdwardsPoint::unflat(o);
+}
+// the exchange step of a sharded MSM: ((p_0 + p_1) + p_2) + ... in index order, one kernel launch
+inline EdwardsPoint fold_ordered(const std::vector<EdwardsPoint>& ps)
+{
+    std::vector<uint64_t> p(ps.size() * 20);
+    for (size_t i = 0; i < ps.size(); i++) ps[i].flat(&p[20 * i]);
+    uint64_t o[20];
+    Backend::check(zc_ed_fold_ordered(Backend::ctx(), p.data(), ps.size(), o), "zc_ed_fold_ordered");
+    return EdwardsPoint::unflat(o);
+}
+// this rank's shard of a global MSM (after Backend::comm_init): all-gather of partial sums + ordered fold
+inline EdwardsPoint msm_sharded(const std::vector<EdwardsPoint>& ps, const std::vector<Scalar>& ks)
+{
+    std::vector<uint64_t> p(ps.size() * 20), k(ks.size() * 5);
+    for (size_t i = 0; i < ps.size(); i++) {
+        ps[i].flat(&p[20 * i]);
+        std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    }
+    uint64_t o[20];
+    Backend::check(zc_msm_sharded(Backend::ctx(), p.data(), k.data(), ps.size(), o), "zc_msm_sharded");
+    return EdwardsPoint::unflat(o);
+}
+// this device's partial sum left in device memory (out_dev: 160 bytes of HIP memory)
+inline void msm_partial(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out_dev)
+{
+    Backend::check(zc_msm_partial(Backend::ctx(), points, scalars, n, out_dev), "zc_msm_partial");
 }
 // k * BASEPOINT from the fixed-base table: equal to `BASEPOINT * k` under == (not limb-identical)
 inline std::vector<EdwardsPoint> mul_base_batch(const std::vector<Scalar>& ks)

@@ -79,8 +79,15 @@ int zc_ctx_destroy(zc_ctx *ctx);
  * torch.cuda.current_stream().cuda_stream; NULL there means the HIP null stream) for
  * device 0 of the context.  external == 0: go back to the context's own stream.   */
 int zc_ctx_set_stream(zc_ctx *ctx, void *hip_stream, int external);
+/* the same for device slot `slot` (index into the `devices` array of zc_ctx_create).  A switch
+ * orders everything already enqueued on the old stream before later work on the new one.       */
+int zc_ctx_set_stream_dev(zc_ctx *ctx, int slot, void *hip_stream, int external);
 int zc_ctx_synchronize(zc_ctx *ctx);
 int zc_device_count(void);
+/* Pin / unpin a caller-owned host buffer (hipHostRegister): host batches from pinned memory copy
+ * asynchronously and skip the runtime's bounce buffers; worth it for buffers reused across calls. */
+int zc_host_register(void *ptr, size_t bytes);
+int zc_host_unregister(void *ptr);
 const char *zc_last_error(void);
 const char *zc_version(void);
 
@@ -182,6 +189,26 @@ int zc_ris_mul_base_compress(zc_ctx *ctx, const uint64_t *k, uint8_t *out32, siz
  * sum of `&P_i * &k_i` as a group element (compare with ==, i.e. affine/compressed). */
 int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
            uint64_t *out_point);
+/* The exchange step of a sharded MSM (BASELINE configs[4]), inside the library.
+ * zc_msm over a context with several device slots already gathers the per-device partial sums
+ * with peer copies and folds them on device slot 0.  For one process per GPU:
+ *   zc_msm_partial      this device's sum, left in DEVICE memory (160 bytes), asynchronous
+ *   zc_ed_fold_ordered  ((p_0 + p_1) + ...) in index order, unified add src/edwards.rs:465-489,
+ *                       ONE kernel launch; host or device pointers
+ *   zc_comm_*           an RCCL communicator owned by the context (librccl is opened on demand):
+ *                       rank 0 calls zc_comm_unique_id, the 128 bytes reach the other ranks by any
+ *                       host transport, every rank calls zc_comm_init
+ *   zc_msm_sharded      local bucket method -> ncclAllGather of the 160-byte partials over xGMI ->
+ *                       ordered fold -> out_point (HOST memory), identical limbs on every rank.
+ *                       (Point addition is not an ncclRedOp_t: all-gather + fold, not all-reduce.) */
+int zc_msm_partial(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
+                   uint64_t *out_dev_point);
+int zc_ed_fold_ordered(zc_ctx *ctx, const uint64_t *parts, size_t count, uint64_t *out);
+int zc_comm_unique_id(uint8_t *id_out128);
+int zc_comm_init(zc_ctx *ctx, const uint8_t *id128, int rank, int world);
+int zc_comm_destroy(zc_ctx *ctx);
+int zc_msm_sharded(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n_local,
+                   uint64_t *out_point);
 
 #ifdef __cplusplus
 }

@@ -528,6 +528,59 @@ impl HipBackend {
         Ok(unflat_ed(&out)[0])
     }
 
+    // -------------------------------------------------------------- sharded MSM: the exchange step
+    /// This device's partial sum, left in device memory (`out_dev`: 160 bytes of HIP memory).
+    pub unsafe fn msm_partial(&self, points: *const u64, scalars: *const u64, n: usize, out_dev: *mut u64) -> Result<()> {
+        check(ffi::zc_msm_partial(self.ctx, points, scalars, n, out_dev))
+    }
+
+    /// `((p_0 + p_1) + p_2) + ...` in index order, one kernel launch.
+    pub fn fold_ordered(&self, parts: &[EdwardsPoint]) -> Result<EdwardsPoint> {
+        let fp = flat_ed(parts);
+        let mut out = vec![0u64; 20];
+        check(unsafe { ffi::zc_ed_fold_ordered(self.ctx, fp.as_ptr(), parts.len(), out.as_mut_ptr()) })?;
+        Ok(unflat_ed(&out)[0])
+    }
+
+    /// Rank 0: the 128-byte RCCL id every rank passes to `comm_init` (any host transport).
+    pub fn comm_unique_id() -> Result<[u8; 128]> {
+        let mut id = [0u8; 128];
+        check(unsafe { ffi::zc_comm_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+
+    pub fn comm_init(&self, id: &[u8; 128], rank: i32, world: i32) -> Result<()> {
+        check(unsafe { ffi::zc_comm_init(self.ctx, id.as_ptr(), rank, world) })
+    }
+
+    pub fn comm_destroy(&self) -> Result<()> {
+        check(unsafe { ffi::zc_comm_destroy(self.ctx) })
+    }
+
+    /// This rank's shard of a global MSM: local bucket method, `ncclAllGather` of the 160-byte
+    /// partial sums, ordered fold on the device; every rank gets the same point.
+    pub fn msm_sharded(&self, p: &[EdwardsPoint], k: &[Scalar]) -> Result<EdwardsPoint> {
+        assert_eq!(p.len(), k.len());
+        let (fp, fk) = (flat_ed(p), flat_sc(k));
+        let mut out = vec![0u64; 20];
+        check(unsafe { ffi::zc_msm_sharded(self.ctx, fp.as_ptr(), fk.as_ptr(), p.len(), out.as_mut_ptr()) })?;
+        Ok(unflat_ed(&out)[0])
+    }
+
+    /// Launch stream of device slot `slot` of a multi-device context.
+    pub unsafe fn set_stream_dev(&self, slot: i32, hip_stream: *mut c_void) -> Result<()> {
+        check(ffi::zc_ctx_set_stream_dev(self.ctx, slot, hip_stream, 1))
+    }
+
+    /// Pin a long-lived host buffer so host batches copy asynchronously.
+    pub unsafe fn host_register(ptr: *mut c_void, bytes: usize) -> Result<()> {
+        check(ffi::zc_host_register(ptr, bytes))
+    }
+
+    pub unsafe fn host_unregister(ptr: *mut c_void) -> Result<()> {
+        check(ffi::zc_host_unregister(ptr))
+    }
+
     // -------------------------------------------------------------- ProjectivePoint (src/edwards.rs:666-998)
     /// `p + q` (`:809-865`).
     pub fn proj_add(&self, p: &[ProjectivePoint], q: &[ProjectivePoint]) -> Result<Vec<ProjectivePoint>> {

@@ -1101,6 +1101,7 @@ void zr_sc_from_bytes_batch(const uint8_t *in, uint64_t *out, uint8_t *ok, size_
 {
     for (size_t i = 0; i < n; i++) {
         int o = zr_sc_from_bytes(FEO(out, i), in + 32 * i);
+        if (!o) *FEO(out, i) = FE_ZERO;                      /* the reference panics: no value (ABI: zero, ok = 0) */
         if (ok) ok[i] = (uint8_t)o;
     }
 }

@@ -79,3 +79,28 @@ def test_cpp_mirror_covers_the_whole_abi():
     hpp = open(os.path.join(ROOT, "dusk_zerocaf_amd", "include", "zerocaf.hpp")).read()
     missing = [s for s in declared_symbols() if s + "(" not in hpp]
     assert not missing, missing
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """The boundary a Rust `extern "C"` block (or cgo, JNI ...) binds must be C-clean: compile
+    include/zerocaf_hip.h as C11 with warnings as errors and call the GPU-free entry points from C."""
+    import dusk_zerocaf_amd as z
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include "zerocaf_hip.h"
+#include <stdio.h>
+int main(void) {
+    zc_ctx *ctx = 0;
+    int (*fn)(zc_ctx *, const uint64_t *, const uint64_t *, uint64_t *, size_t, unsigned) = zc_ed_scalar_mul;
+    printf("%s|%d|%d\\n", zc_version(), zc_device_count() >= 0, fn != 0);
+    if (zc_device_count() == 0) return zc_ctx_create(0, 0, &ctx) == ZC_ERR_NO_DEVICE ? 0 : 3;
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(z.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lzerocaf_hip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.startswith("zerocaf_hip") and out.strip().endswith("|1|1")

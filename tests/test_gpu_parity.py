@@ -667,7 +667,7 @@ def test_msm_bucket_method(eng, oracle, n, bits):
 
 
 def test_msm_window_widths_vs_oracle(eng, oracle, monkeypatch):
-    """Window widths c = 10..16 (forced with ZC_MSM_WINDOW; the natural choice at 2^16 pairs is 12)
+    """Window widths c = 5..19 (forced with ZC_MSM_WINDOW; the natural choice at 2^16 pairs is 13)
     against the ORACLE's sum of the reference's Mul<Scalar> + Add (edwards.rs:547-561, :465-489)."""
     n = (1 << 16) + 11
     P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 87, bits=249))
@@ -676,10 +676,46 @@ def test_msm_window_widths_vs_oracle(eng, oracle, monkeypatch):
     P[30] = V.IDENT_ROW
     want = oracle.msm_naive_mt(P, K)
     wenc = oracle.ed_compress(want)[0]
-    for c in (10, 12, 13, 14, 15, 16):
+    for c in (5, 10, 12, 13, 14, 15, 16, 17, 19):
         monkeypatch.setenv("ZC_MSM_WINDOW", str(c))
         got = eng.msm(P, K)
         assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), c
+
+
+def test_msm_skewed_digit_distributions(eng, oracle, monkeypatch):
+    """The bucket sums are a segmented reduction of the sorted (bucket, point) list in fixed-length
+    runs, so skew costs nothing and must change nothing: every scalar equal (one bucket per window
+    holds all n points), scalars of a few bits (most windows empty), a two-valued mix, and run lengths
+    from 4 upward (many reduction levels, every edge case of run / bucket alignment)."""
+    n = 20000
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 91, bits=249))
+    rng = np.random.default_rng(V.SEED + 92)
+    cases = {}
+    K = np.tile(V.rand_scalars_np(1, V.SEED + 93, bits=249), (n, 1))
+    cases["all_equal"] = K
+    K = np.zeros((n, 5), dtype=np.uint64)
+    K[:, 0] = rng.integers(0, 8, size=n, dtype=np.uint64)
+    cases["three_bits"] = K
+    K = np.tile(V.rand_scalars_np(2, V.SEED + 94, bits=252), (n // 2, 1))
+    K[::7] = 0
+    cases["two_values_and_zeros"] = K
+    K = V.rand_scalars_np(n, V.SEED + 95, bits=249)
+    K[:, 4] = 0                                                   # 208-bit scalars: top windows empty
+    cases["short"] = K
+    for name, K in cases.items():
+        want = oracle.msm_naive_mt(P, K)
+        wenc = oracle.ed_compress(want)[0]
+        for run, c in ((None, None), (4, 8), (5, 11), (7, None), (64, 6), (4096, None)):
+            if run is None:
+                monkeypatch.delenv("ZC_MSM_RUN", raising=False)
+            else:
+                monkeypatch.setenv("ZC_MSM_RUN", str(run))
+            if c is None:
+                monkeypatch.delenv("ZC_MSM_WINDOW", raising=False)
+            else:
+                monkeypatch.setenv("ZC_MSM_WINDOW", str(c))
+            got = eng.msm(P, K)
+            assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), (name, run, c)
 
 
 def test_msm_config5_shard_2_21_vs_oracle(eng, oracle):
@@ -825,3 +861,111 @@ def test_concurrent_callers_share_a_context(eng, oracle):
     assert not errs, errs
     for name in want:
         assert eq(got[name], want[name]), name
+
+
+def test_msm_exchange_inside_the_library(eng, oracle):
+    """SURVEY 8e / BASELINE configs[4]: partial sums stay in HBM, are gathered on the device (peer
+    copies inside one process, ncclAllGather between processes) and folded in rank order by ONE
+    kernel.  Exercised here on one GPU: two device slots of the same GPU, the library's own RCCL
+    communicator with world size 1, and torch.distributed's `nccl` backend with world size 1."""
+    import torch
+    import torch.distributed as dist
+    import dusk_zerocaf_amd as z
+    from dusk_zerocaf_amd import distributed as D
+    n = 9000
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 170, bits=249))
+    K = V.rand_scalars_np(n, V.SEED + 171, bits=252)
+    want = oracle.msm_naive_mt(P, K)
+    wenc = oracle.ed_compress(want)[0]
+    # ordered fold: limb-exact against the oracle's sequential unified adds, host and device pointers
+    parts = oracle.ed_scalar_mul(P[:7], K[:7])
+    acc = parts[0:1]
+    for i in range(1, 7):
+        acc = oracle.ed_add(acc, parts[i:i + 1])
+    assert eq(eng.ed_fold_ordered(parts), acc) and eq(eng.ed_fold_ordered(parts[:1]), parts[:1])
+    dparts = torch.from_numpy(parts.view(np.int64)).cuda()
+    assert eq(eng.ed_fold_ordered(dparts).cpu().numpy().view(np.uint64), acc)
+    # partial sum left on the device
+    dP, dK = torch.from_numpy(P.view(np.int64)).cuda(), torch.from_numpy(K.view(np.int64)).cuda()
+    part = eng.msm_partial(dP, dK)
+    torch.cuda.synchronize()
+    assert part.is_cuda and eq(oracle.ed_compress(part.cpu().numpy().view(np.uint64))[0], wenc)
+    # two device slots in one process: per-slot partials -> peer/device copies -> fold kernel on slot 0
+    two = z.Engine([0, 0])
+    try:
+        got = two.msm(P, K)
+        halves = [oracle.msm_naive_mt(P[:4500], K[:4500]), oracle.msm_naive_mt(P[4500:], K[4500:])]
+        assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc)
+        assert oracle.ed_eq(got, oracle.ed_add(halves[0], halves[1]))[0] == 1
+    finally:
+        two.close()
+    # the library's own RCCL communicator (world size 1 executes ncclAllGather + the fold)
+    one = z.Engine()
+    try:
+        D.init_library_comm(one)
+        got = D.msm_sharded_rccl(one, P, K)
+        assert eq(oracle.ed_compress(got)[0], wenc)
+        got = one.msm_sharded(dP, dK)                              # device-resident shard
+        assert eq(oracle.ed_compress(got)[0], wenc)
+        assert eq(one.msm_sharded(P[:0], K[:0]), np.array([V.IDENT_ROW], dtype=np.uint64))
+        one.comm_destroy()
+    finally:
+        one.close()
+    # torch.distributed `nccl` (= RCCL) moving device rows, fold on the device
+    import os
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rows = D.all_gather_rows(part)
+        assert rows.is_cuda and rows.shape == (1, 20)
+        got = D.msm_sharded(dP, dK, None, engine=eng)
+        assert eq(oracle.ed_compress(got)[0], wenc)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stream_switch_and_torch_stream_following(eng, oracle):
+    """Calls on torch tensors follow torch's current stream unless a stream was pinned; switching
+    streams orders earlier work (and shared scratch) with an event instead of a host sync."""
+    import torch
+    import dusk_zerocaf_amd as z
+    n = 1 << 15
+    P = V.base_multiples(oracle, 512, V.SEED + 180)
+    P = np.tile(P, (n // 512, 1))
+    K = V.rand_scalars_np(n, V.SEED + 181, bits=252)
+    want = oracle.mt(oracle.ed_scalar_mul, P, K)
+    wenc = oracle.ris_compress(want)
+    e = z.Engine()
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                              # inputs produced on a side stream
+            dP = torch.from_numpy(P.view(np.int64)).cuda(non_blocking=True)
+            dK = torch.from_numpy(K.view(np.int64)).cuda(non_blocking=True)
+            out = e.ed_scalar_mul(dP, dK)                          # follows `side`
+            enc1 = e.ris_compress(out)
+        side.synchronize()
+        assert eq(out.cpu().numpy().view(np.uint64), want) and eq(enc1.cpu().numpy(), wenc)
+        # back-to-back launches that share the window-table scratch, on two different streams, no sync between
+        encs = oracle.ris_compress(P)
+        denc = torch.from_numpy(encs).cuda()
+        torch.cuda.synchronize()
+        r1, ok1 = e.ris_roundtrip_mul(denc, dK)                    # current (default) stream
+        with torch.cuda.stream(side):
+            r2, ok2 = e.ris_roundtrip_mul(denc, dK)                # switches to `side`: ordered by an event
+        torch.cuda.synchronize()
+        wout, wok = oracle.mt(oracle.ris_roundtrip_mul, encs, K)
+        assert eq(r1.cpu().numpy(), wout) and eq(r2.cpu().numpy(), wout) and eq(ok1.cpu().numpy(), wok)
+    finally:
+        e.close()
+
+
+def test_scalar_from_bytes_failed_rows_are_zero(eng, oracle):
+    raw = np.frombuffer(pm.L.to_bytes(32, "little") + (pm.L - 1).to_bytes(32, "little") + b"\xff" * 32, dtype=np.uint8).reshape(3, 32)
+    out, ok = eng.sc_from_bytes(raw)
+    assert ok.tolist() == [0, 1, 0] and not out[0].any() and not out[2].any() and eq(out[1], V.limbs_array([pm.L - 1])[0])
+    wout, wok = oracle.sc_from_bytes(raw)
+    assert eq(out, wout) and eq(ok, wok)
