@@ -277,7 +277,7 @@ def main():
         sample = per_core * _z.host_threads()
     if sample:
         v, cores, secs, total, want = cpu_baseline(wl, sample, data, n)
-        k = min(len(want), n) if wl != "msm" else 0
+        k = 0 if wl == "msm" else min(len(want[0] if wl == "ristretto" else want), n)
         if wl == "scalar_mul":
             torch.cuda.synchronize()
             got = out[:k].cpu().numpy().view(np.uint64)

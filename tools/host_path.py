@@ -62,6 +62,30 @@ def main():
                           "fresh_ms": round(tf * 1e3, 2), "device_ms": round(t_dev * 1e3, 2),
                           "warm_units_per_s": round(n / tw)}))
 
+    # Two device slots on the same GPU: the slots' uploads are issued by one worker thread each, so
+    # they run side by side; pinned (zc_host_register) buffers copy asynchronously in any case.
+    # A copy-bound op (fe_mul: 120 B over PCIe per 100 ns of kernel) shows the issue order best.
+    os.environ.pop("ZC_HOST_CHUNKS", None)
+    a, b = rand_scalars_np(n, 9, 252), rand_scalars_np(n, 10, 252)
+    o = np.empty_like(a)
+    for slots in (1, 2):
+        e2 = z.Engine([0] * slots)
+        for pinned in (False, True):
+            bufs = (P, k, out, a, b, o)
+            if pinned:
+                for x in bufs:
+                    z.Engine.host_register(x)
+            t_sm = best(lambda: e2._call("zc_ed_scalar_mul", P.ctypes.data, k.ctypes.data, out.ctypes.data, n, 0))
+            assert np.array_equal(out, ref)
+            t_fe = best(lambda: e2._call("zc_fe_mul", a.ctypes.data, b.ctypes.data, o.ctypes.data, n))
+            if pinned:
+                for x in bufs:
+                    z.Engine.host_unregister(x)
+            print(json.dumps({"slots": slots, "host_memory": "pinned (zc_host_register)" if pinned else "pageable", "n": n,
+                              "ed_scalar_mul_ms": round(t_sm * 1e3, 2), "fe_mul_ms": round(t_fe * 1e3, 2),
+                              "fe_mul_GBps_over_pcie": round(120 * n / t_fe / 1e9, 1)}))
+        e2.close()
+
 
 if __name__ == "__main__":
     main()
