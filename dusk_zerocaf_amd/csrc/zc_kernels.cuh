@@ -556,6 +556,42 @@ ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64*
 {
     ed_scalar_mul_body<false>(p, k, k_stride, out, idx, n);
 }
+// Persistent waves for large batches (the headline shape).  A grid of 3 workgroups per CU stays
+// resident; every WAVE, on its own, pulls the next tile of 64 elements from an atomic counter until
+// the batch is done.  Tiles are 64 consecutive entries of the batch-wide cost-sorted permutation
+// (k_sm_cost_*, most expensive first), so
+//   * the 64 lanes of a wave carry scalars of (almost) the same cost bitlen - 1 + popcount: a wave
+//     performs the mean number of formula evaluations, not the maximum over a block-local quartile;
+//   * no wave waits for the three other waves of a workgroup (a new workgroup needs a free slot on
+//     all four SIMDs at once: with one tile per workgroup the cheapest quartile's SIMD idles until
+//     the dearest quartile is done), and no partial last round of workgroups: the chip drains
+//     within one tile's run time, the cheapest tiles last.
+// Records are gathered through the permutation (160-byte points, 40-byte scalars: whole-line
+// gathers roughly double the 210 MB read per 2^20, still ~0.3 % of the HBM roof).  Scalar words live
+// in the wave's own 9 x 64-word LDS region; LDS operations of one wave execute in order, so no
+// barrier is needed anywhere.  Results are the same limbs as k_ed_scalar_mul's (same per-lane loop).
+ZC_KERNEL void k_ed_scalar_mul_pw(const u64* p, const u64* k, u64* out, const u32* idx, u32* counter, u32 n)
+{
+    __shared__ u32 sk[9 * ZC_BLOCK];
+    const int lane = threadIdx.x & 63;
+    u32* skw = sk + 9 * (threadIdx.x & ~63) + lane;        // word j of this lane: skw[64 j]
+    const u32 ntiles = (n + 63) / 64;
+    for (;;) {
+        u32 t = 0;
+        if (lane == 0) t = atomicAdd(counter, 1u);
+        t = (u32)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= ntiles) break;
+        const u32 i = t * 64 + lane;
+        const bool valid = i < n;
+        const size_t own = valid ? (size_t)idx[i] : 0;
+        u64 l[5];
+        load_scalar(l, k + 5 * own);
+        int nbits;
+        scalar_to_words(skw, 64, l, nbits);
+        const pt Q = scalar_mul_unified<false>(pt_load(p + 20 * own), skw, 64, valid ? nbits : 0);
+        if (valid) pt_store(out + 20 * own, Q);
+    }
+}
 // the same for launches of at most a few hundred workgroups (one wave per SIMD): independent-chain multiplier
 ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
 {
@@ -595,6 +631,7 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
     const int tid = threadIdx.x;
+    const u32 wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u32 i = blockIdx.x * ZC_BLOCK + tid;             // a launch is at most FAST_CHUNK_LANES elements
     const bool valid = i < n;
     const u32 ii = valid ? i : 0;
@@ -610,10 +647,13 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
     Q = pt_select(dec, Q, pt_identity());
     fe_to_words256(w, ris_compress(Q));
     if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
-    // the output address is formed here, from the hardware ids again, instead of staying live (as a
-    // 64-bit pair the register allocator would spill) across the three exponentiation-sized phases
-    u32 i_late = blockIdx.x * ZC_BLOCK + threadIdx.x;
-    asm volatile("" : "+v"(i_late));
+    // The output index is formed again here from values that occupy no vector register in between:
+    // the wave's number inside the workgroup sits in an SGPR since the kernel's first instruction and
+    // the lane number comes from v_mbcnt (a function of the lane position alone).  threadIdx.x itself
+    // is a live-in VGPR, and anything derived from it stays live -- and gets spilled -- across the
+    // three exponentiation-sized phases.
+    const u32 lane_late = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const u32 i_late = blockIdx.x * ZC_BLOCK + wave_in_block * 64u + lane_late;
     if (i_late < n) {
         store_words256(out + 32 * (size_t)i_late, w);
         if (ok) ok[i_late] = dec ? 1 : 0;

@@ -341,18 +341,28 @@ inline bool global_balance()
     static const bool g = [] { const char* e = getenv("ZC_BALANCE"); return e && std::string(e) == "global"; }();
     return g;
 }
-const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt)
+constexpr size_t BAL_COUNTERS = 64;                       // u32 work counters of the persistent kernels, after the bins
+const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt, bool force = false, zc::u32** counter = nullptr)
 {
-    if (!global_balance() || cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
-    const size_t need = zc::ZC_COST_BINS * sizeof(zc::u32) + cnt * sizeof(zc::u32);
+    if ((!force && !global_balance()) || cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
+    const size_t need = (zc::ZC_COST_BINS + BAL_COUNTERS + cnt) * sizeof(zc::u32);
     if (ensure(&D.bal, &D.bal_bytes, need) != ZC_OK) return nullptr;
     zc::u32* hist = (zc::u32*)D.bal;
-    zc::u32* idx = hist + zc::ZC_COST_BINS;
-    if (hipMemsetAsync(hist, 0, zc::ZC_COST_BINS * sizeof(zc::u32), D.s()) != hipSuccess) return nullptr;
+    zc::u32* idx = hist + zc::ZC_COST_BINS + BAL_COUNTERS;
+    if (hipMemsetAsync(hist, 0, (zc::ZC_COST_BINS + BAL_COUNTERS) * sizeof(zc::u32), D.s()) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(zc::k_sm_cost_hist, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), k, hist, cnt);
     hipLaunchKernelGGL(zc::k_sm_cost_scan, dim3(1), dim3(zc::ZC_BLOCK), 0, D.s(), hist);
     hipLaunchKernelGGL(zc::k_sm_cost_scatter, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), k, hist, idx, cnt);
+    if (counter) *counter = hist + zc::ZC_COST_BINS;
     return idx;
+}
+// Strict scalar-mul batches from this size on run on persistent waves over the cost-sorted
+// permutation (k_ed_scalar_mul_pw); ZC_SCHED=block keeps one workgroup per 256 elements.
+constexpr size_t PW_MIN_ELEMS = (size_t)1 << 17;
+inline bool persistent_waves()
+{
+    static const bool on = [] { const char* e = getenv("ZC_SCHED"); return !(e && std::string(e) == "block"); }();
+    return on;
 }
 
 // Launches of at most one workgroup per CU keep a single wave on every SIMD; a lone wave cannot
@@ -408,6 +418,14 @@ int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t*
     REQUIRE(p); REQUIRE(k); REQUIRE(out);
     Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        if (cnt >= PW_MIN_ELEMS && persistent_waves()) {
+            zc::u32* counter = nullptr;
+            if (const zc::u32* perm = balance_index(D, (const u64*)d[1], cnt, true, &counter)) {
+                hipLaunchKernelGGL(zc::k_ed_scalar_mul_pw, dim3((unsigned)(3 * D.cus)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1],
+                                   (u64*)d[2], perm, counter, (zc::u32)cnt);
+                return;
+            }
+        }
         const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
         if (cnt <= QUAD_LAUNCH_ELEMS && !idx) {
             // four lanes per element: the batch cannot fill the chip anyway, so buy latency with lanes

@@ -307,11 +307,12 @@ def test_scalar_mul_strict_limbs(eng, oracle, n, bits):
     assert eq(eng.ed_scalar_mul(P, K), oracle.ed_scalar_mul(P, K))
 
 
-@pytest.mark.parametrize("n", [(1 << 14) + 1, 40000, (1 << 16) + 1])
+@pytest.mark.parametrize("n", [(1 << 14) + 1, 40000, (1 << 16) + 1, (1 << 17) + 77])
 def test_scalar_mul_strict_launch_shapes(eng, oracle, n):
     """The strict path picks its kernel by batch size: four lanes per element up to 2^14 (covered
-    above), the independent-chain variant up to 256 workgroups, the default kernel beyond.  The two
-    larger shapes against the oracle on slices (head, middle, ragged tail)."""
+    above), the independent-chain variant up to 256 workgroups, one workgroup per 256 elements up to
+    2^17, persistent waves over the cost-sorted permutation from 2^17 on (ragged last tile, zero and
+    raw >= 2^256 scalars among the costs).  Against the oracle on slices (head, middle, ragged tail)."""
     base = V.base_multiples(oracle, 1500, V.SEED + 44)
     P = np.tile(base, (n // 1500 + 1, 1))[:n].copy()
     K = V.rand_scalars_np(n, V.SEED + 45 + n, bits=252)
