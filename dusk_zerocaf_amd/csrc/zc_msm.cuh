@@ -33,7 +33,9 @@
 #include "zc_quad.cuh"
 
 #ifndef ZC_MSM_ACC_ILP
-#define ZC_MSM_ACC_ILP true    // bucket sums on the independent-chain multiplier (A/B knob)
+#define ZC_MSM_ACC_ILP false   // bucket sums on the column-ordered multiplier: with fixed-length runs every wave has
+                               // three neighbours to overlap with (2^24 pairs: 25.1 -> 24.7 ms against the
+                               // independent-chain form, which paid off when one lane owned one bucket)
 #endif
 
 namespace zc {
@@ -81,9 +83,10 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
     niels_store(cached + 32 * i, niels_from_pt(pt_load(points + 20 * i)));
 }
 // Bucket sums are kept in the kernels' own number system between k_msm_runs and k_msm_segments:
-// 36 x u32 (X, Y, Z, T as nine 29-bit Montgomery limbs each, R-class), 144 bytes per bucket.  The
-// array is zero-filled first; Z == 0 never occurs for a point, so an all-zero record reads as the
-// identity (an empty bucket).
+// 36 x u32 (X, Y, Z, T as nine 29-bit Montgomery limbs each, R-class), 144 bytes per bucket.  A
+// one-byte flag per bucket (zero-filled per call: 144 times less than the records) says whether the
+// record was written; an unwritten bucket is the identity.  In the edge lists an all-zero record
+// stands for the identity (Z == 0 never occurs for a point).
 constexpr int MSM_RAW_WORDS = 36;
 ZC_DI void pt_store_raw(u32* __restrict__ o, const pt& p)
 {
@@ -126,15 +129,17 @@ ZC_DI void raw_store_zero(u32* __restrict__ o)
 //   * otherwise it becomes an edge of the next level, in the same raw format: slot 2j (open to the
 //     left) or 2j + 1 (open to the right only); a run that is one segment open on both sides fills
 //     both slots (the second with an all-zero record = identity) so that no unused slot ever
-//     separates two edges of one bucket.  Unused slots keep the sentinel key the host pre-filled
-//     (0xFFFFFFFF >= nbuckets); zero digits carry a sentinel key too and are dropped here.
+//     separates two edges of one bucket.  Unused slots keep the sentinel key 0xFFFFFFFF >= nbuckets
+//     every lane writes into its two slots first; zero digits carry a sentinel key too and are
+//     dropped here.
 ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 prev_key, u32 next_key, u32 j, u32 nbuckets,
-                     u32* __restrict__ buckets_raw, u32* __restrict__ next_keys, u32* __restrict__ next_recs)
+                     u32* __restrict__ buckets_raw, uint8_t* __restrict__ present, u32* __restrict__ next_keys, u32* __restrict__ next_recs)
 {
     if (key >= nbuckets) return;
     const bool open_left = seg_first && key == prev_key;
     const bool open_right = seg_last && key == next_key;
     u32* dst = buckets_raw + MSM_RAW_WORDS * (size_t)key;
+    if (!(open_left || open_right)) present[key] = 1;
     if (open_left || open_right) {
         const size_t slot = open_left ? 2 * (size_t)j : 2 * (size_t)j + 1;
         next_keys[slot] = key;
@@ -155,9 +160,12 @@ ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 
 // holds no VGPRs and the kernel fits four waves per SIMD (32 KB of LDS per block, 4 blocks per CU).
 // A lane reads and overwrites only its own slots: lgkmcnt(0) before the next copy is issued,
 // vmcnt(0) before the slots are read.
-extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+#ifndef ZC_MSM_WAVES
+#define ZC_MSM_WAVES 4         // resident waves per SIMD the bucket-sum kernel is compiled for (A/B knob)
+#endif
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                u32* buckets_raw, u32* next_keys, u32* next_recs)
+                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
 {
     __shared__ uint4 stage[8 * ZC_BLOCK];
     const int lane = threadIdx.x & 63;
@@ -168,6 +176,8 @@ void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T
     const u32 lo = (u32)lo64;
     const u32 hi = (len - lo > T) ? lo + T : len;
     const u32 none = 0xFFFFFFFFu;
+    next_keys[2 * (size_t)j] = none;                           // this lane's two edge slots: unused until msm_flush says otherwise
+    next_keys[2 * (size_t)j + 1] = none;
     u32 cur_key = keys[lo];
     if (cur_key >= nbuckets) return;                           // zero digits sort behind every bucket: nothing to add
     const u32 prev_key = lo > 0 ? keys[lo - 1] : none;
@@ -200,7 +210,7 @@ void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T
         acc = pt_add_cached<ZC_MSM_ACC_ILP>(acc, niels_cond_neg(neg, cur));
         const bool last = e + 1 == hi;
         if (last || knext != cur_key) {                        // the segment ends with this entry
-            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, next_keys, next_recs);
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
             acc = pt_identity();
             first = false;
             cur_key = knext;
@@ -216,11 +226,13 @@ void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T
 // at the level above left its two edges in slots 2j + 1 and 2j + 2, and with an even T that pair always
 // lies inside one run here, so everything but the buckets longer than a run is finished at level 1.
 ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                                u32* buckets_raw, u32* next_keys, u32* next_recs)
+                                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
 {
     const u32 j = blockIdx.x * ZC_BLOCK + threadIdx.x;
     const u64 lo64 = j ? (u64)j * T + 1 : 0;
     if (lo64 >= len) return;
+    next_keys[2 * (size_t)j] = 0xFFFFFFFFu;
+    next_keys[2 * (size_t)j + 1] = 0xFFFFFFFFu;
     const u32 lo = (u32)lo64;
     const u64 hi64 = (u64)(j + 1) * T + 1;
     const u32 hi = hi64 < len ? (u32)hi64 : len;
@@ -235,7 +247,7 @@ ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T
         const bool last = e + 1 == hi;
         const u32 knext = last ? none : keys[e + 1];
         if (last || knext != cur_key) {
-            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, next_keys, next_recs);
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
             acc = pt_identity();
             first = false;
             cur_key = knext;
@@ -248,14 +260,16 @@ ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T
 //   acc = sum_j B_{first+j},  sum = sum_j (j + 1) B_{first+j}   (running sums from the top bucket down)
 // so that  sum_j (first' + j + 1) B_{first+j} = sum + first' * acc  with first' = first mod 2^(c-1).
 // Emits sum, acc and the scalar first'.
-ZC_KERNEL void k_msm_segments(const u32* buckets_raw, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c)
+ZC_KERNEL void k_msm_segments(const u32* buckets_raw, const uint8_t* present, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c)
 {
     const size_t s = gid();
     if (s >= nseg_total) return;
     const size_t first = s * MSM_SEG;                     // global bucket index of the segment start
     pt acc = pt_identity(), sum = pt_identity();
     for (int j = MSM_SEG - 1; j >= 0; j--) {
-        acc = pt_add<true>(acc, pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j)));
+        pt b = pt_identity();
+        if (present[first + j]) b = pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j));
+        acc = pt_add<true>(acc, b);
         sum = pt_add<true>(sum, acc);
     }
     pt_store(seg_sum + 20 * s, sum);
@@ -263,6 +277,29 @@ ZC_KERNEL void k_msm_segments(const u32* buckets_raw, u64* seg_sum, u64* seg_acc
     u64* k = seg_scalar + 5 * s;
     k[0] = (u64)(first & (((size_t)1 << (c - 1)) - 1));
     k[1] = 0; k[2] = 0; k[3] = 0; k[4] = 0;
+}
+
+// One workgroup folds `g` consecutive points (g a power of two, 2 <= g <= 512) into one: pairs on
+// load, then a tree in LDS (raw 144-byte records).  Two launches take the 2^(c-5) segment sums of
+// every window down to one point per window, where the pairwise kernel needed c - 5 launches of
+// a few microseconds of work each.  Groups never straddle windows (both counts are powers of two).
+ZC_KERNEL void k_msm_fold_groups(const u64* in, u64* out, u32 g)
+{
+    __shared__ uint4 sraw[9 * ZC_BLOCK];
+    u32* mine = reinterpret_cast<u32*>(sraw) + MSM_RAW_WORDS * threadIdx.x;
+    const u32 t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * g;
+    u32 live = g / 2;
+    if (t < live) pt_store_raw(mine, pt_add<true>(pt_load(in + 20 * (base + 2 * t)), pt_load(in + 20 * (base + 2 * t + 1))));
+    while (live > 1) {
+        __syncthreads();
+        live >>= 1;
+        pt s;
+        if (t < live) s = pt_add<true>(pt_load_raw(mine), pt_load_raw(mine + MSM_RAW_WORDS * live));
+        __syncthreads();
+        if (t < live) pt_store_raw(mine, s);
+    }
+    if (t == 0) pt_store(out + 20 * (size_t)blockIdx.x, pt_load_raw(mine));
 }
 
 // ---------------------------------------------------------------- window combination

@@ -548,6 +548,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         char* tmp = cv.take<char>(sort_tmp);
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
+        uint8_t* present = cv.take<uint8_t>(nb);
         zc::u32* ekeys[2] = {cv.take<zc::u32>(2 * nl0), cv.take<zc::u32>(2 * nl0)};       // edge lists, ping-pong
         zc::u32* erecs[2] = {cv.take<zc::u32>(2 * nl0 * zc::MSM_RAW_WORDS), cv.take<zc::u32>(2 * nl0 * zc::MSM_RAW_WORDS)};
         u64* seg_sum = cv.take<u64>(nseg * 20);
@@ -564,7 +565,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         size_t st = sort_tmp;
         HIP_TRY(rocprim::radix_sort_pairs(tmp, st, kb, vb, m, 0, (unsigned)keybits, D.s()));
         hipLaunchKernelGGL(zc::k_msm_prepare, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
-        HIP_TRY(hipMemsetAsync(buckets, 0, nb * zc::MSM_RAW_WORDS * sizeof(zc::u32), D.s()));   // all-zero record = empty bucket
+        HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
         // bucket sums: segmented reduction of the sorted list in runs of T, level by level
         {
             const zc::u32* lk = kb.current();
@@ -576,13 +577,12 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 const size_t nl = level ? (len <= t + 1 ? 1 : (len - 1 + t - 1) / t) : (len + t - 1) / t;
                 zc::u32* nk = ekeys[level & 1];
                 zc::u32* nr = erecs[level & 1];
-                if (nl > 1) HIP_TRY(hipMemsetAsync(nk, 0xFF, 2 * nl * sizeof(zc::u32), D.s()));
                 if (level == 0)
                     hipLaunchKernelGGL(zc::k_msm_runs, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, (const zc::u32*)vb.current(), (const zc::u32*)cached,
-                                       (zc::u32)len, (zc::u32)t, (zc::u32)nb, buckets, nk, nr);
+                                       (zc::u32)len, (zc::u32)t, (zc::u32)nb, buckets, present, nk, nr);
                 else
                     hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
-                                       buckets, nk, nr);
+                                       buckets, present, nk, nr);
                 if (nl <= 1) break;                        // one lane saw the whole list: nothing is left open
                 if (level > 40) return fail(ZC_ERR_HIP, "zc_msm: segmented reduction did not converge");
                 lk = nk;
@@ -590,18 +590,20 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 len = 2 * nl;
             }
         }
-        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)buckets, seg_sum, seg_acc, seg_k, nseg, c);
+        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)buckets, (const uint8_t*)present, seg_sum, seg_acc, seg_k, nseg, c);
         // seg_acc <- (first mod 2^(c-1)) * seg_acc ; seg_sum <- seg_sum + seg_acc
         hipLaunchKernelGGL(strict_kernel_for(nseg), dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
                            seg_acc, (const zc::u32*)nullptr, nseg);
         hipLaunchKernelGGL(zc::k_ed_add, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_sum, (const u64*)seg_acc, seg_sum, nseg);
-        // fold every window's nseg/W segment sums (power of two per window: pairs never straddle windows)
+        // fold every window's nseg/W segment sums (a power of two per window) to one point per window:
+        // one workgroup per group of up to 512 points, two launches at most
         size_t left = nseg;
         u64* cur = seg_sum;
         u64* nxt = fold_b;
         while (left > (size_t)W) {
-            hipLaunchKernelGGL(zc::k_ed_fold_pairs, dim3(grid_for(left / 2)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, nxt, left);
-            left /= 2;
+            const size_t g = std::min<size_t>(512, left / (size_t)W);
+            hipLaunchKernelGGL(zc::k_msm_fold_groups, dim3((unsigned)(left / g)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, nxt, (zc::u32)g);
+            left /= g;
             std::swap(cur, nxt);
         }
         // sum_w 2^(c w) S_w
