@@ -26,7 +26,7 @@ roofline: the scalar-mul / Ristretto / MSM kernels are bound by the integer mult
 `frac_useful` counts only the multiplications the reference's formula sequence needs (computed from
 the actual scalars of this run: sum of bitlen - 1 + popcount formula evaluations x 9 multiplications
 x 135 v_mad_u64_u32) -- no profile input at all.  The PMC-derived fields are dropped (null, with a
-note) when the profile was taken on another build of the library (sha256 mismatch).  The HBM view
+note) when the profile was taken on other kernel sources than the tree's (sha256 of csrc/ + the header).  The HBM view
 (algorithmic bytes / time vs 8 TB/s, PMC traffic) is kept under `hbm`.  fe_mul is HBM-bound: `bound` = "hbm".
 """
 from __future__ import annotations
@@ -47,10 +47,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 MADS_PER_MUL = 135               # v_mad_u64_u32 per Montgomery multiplication (zc_arith.cuh, column-ordered)
 WORKLOADS = {
     # algorithmic bytes per unit: SURVEY 8(d)
-    "scalar_mul": {"bytes": 360, "kernel": "k_ed_scalar_mul", "bound": "valu_int_mul", "unit": "scalar-muls/s"},
+    "scalar_mul": {"bytes": 360, "kernel": "k_ed_scalar_mul_pw (+ k_sm_cost_hist/scan/scatter)", "bound": "valu_int_mul", "unit": "scalar-muls/s"},
     "fe_mul": {"bytes": 120, "kernel": "k_fe_mul", "bound": "hbm", "unit": "field-muls/s"},
     "ristretto": {"bytes": 104, "kernel": "k_ris_roundtrip_mul_fast", "bound": "valu_int_mul", "unit": "round-trips/s"},
-    "msm": {"bytes": 200, "kernel": "k_msm_accumulate (+ rocPRIM radix sort, k_msm_segments, folds, k_msm_window_combine)",
+    "msm": {"bytes": 200, "kernel": "k_msm_runs (+ rocPRIM radix sort, k_msm_prepare/digits/runs_edges/segments/fold_groups/window_combine)",
             "bound": "valu_int_mul", "unit": "pairs/s"},
 }
 
@@ -120,10 +120,13 @@ def roofline_inputs(lib_path):
     if not os.path.exists(path):
         return None, "profiles/roofline_inputs.json missing"
     inp = json.load(open(path))
-    sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
-    if inp.get("lib_sha256") != sha:
-        return inp, "profile taken on another build of libzerocaf_hip.so (sha256 %s..., loaded %s...): PMC-derived fields dropped" % (
-            str(inp.get("lib_sha256"))[:12], sha[:12])
+    from dusk_zerocaf_amd import build as zbuild
+    sha = zbuild.sources_sha256()
+    if os.environ.get("ZC_LIB_PATH") or zbuild.stale():
+        return inp, "the loaded library is not a build of the kernel sources in the tree: PMC-derived fields dropped"
+    if inp.get("kernel_sources_sha256") != sha:
+        return inp, "profile taken on other kernel sources (sha256 %s..., tree %s...): PMC-derived fields dropped" % (
+            str(inp.get("kernel_sources_sha256"))[:12], sha[:12])
     return inp, None
 
 

@@ -21,6 +21,16 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 library)")
 
 
+def sources_sha256() -> str:
+    """sha256 over the kernel sources and the ABI header (DEPS, in order): identifies what a library was
+    built from independently of the build (profiles/roofline_inputs.json is keyed by it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(open(os.path.join(CSRC, d), "rb").read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True

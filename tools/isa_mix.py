@@ -5,7 +5,7 @@ Compiles the library source to gfx950 assembly (hipcc -S --cuda-device-only, no 
 the largest backward-branch loop of the kernel and counts opcodes.  Writes the JSON named by --out (profiles/rNN_isa_mix.json),
 which tools/make_roofline_inputs.py uses to split the PMC instruction count into the multiplier-rate class
 (v_mad_u64_u32, v_mul_lo_u32, 64-bit shifts: ~5 cycles per wave-instruction per SIMD) and the rest.
-Usage: python tools/isa_mix.py [kernel[:whole] ...] [--out profiles/rNN_isa_mix.json]
+Usage: python tools/isa_mix.py [kernel[:whole|:inner] ...] [--out profiles/rNN_isa_mix.json]
 """
 import collections
 import json
@@ -28,9 +28,11 @@ def compile_asm():
         return open(asm).read()
 
 
-def mix(text, kernel, whole=False):
+def mix(text, kernel, whole=False, inner=False):
     """Opcode counts of the kernel's largest inner loop (whole=True: of the whole kernel body, every
-    instruction counted once -- for kernels whose time is spread over several loops of the same make-up)."""
+    instruction counted once -- for kernels whose time is spread over several loops of the same make-up;
+    inner=True: the smallest loop that still holds >= 1000 v_mad_u64_u32 -- the step loop of a kernel
+    whose outermost loop walks tiles)."""
     i0 = text.index("\n%s:" % kernel)
     body = text[i0:text.index(".Lfunc_end", i0)]
     lines = []
@@ -47,6 +49,9 @@ def mix(text, kernel, whole=False):
     # the step loop: the largest loop that is nested in the (slightly larger) per-block loop, if any
     loops.sort(reverse=True)
     size, a, b = loops[1] if len(loops) > 1 and loops[1][0] > 0.9 * loops[0][0] else loops[0]
+    if inner:
+        cands = [(sz, x, y) for sz, x, y in loops if sum(1 for l in lines[x:y] if l.startswith("v_mad_u64_u32")) >= 1000]
+        size, a, b = min(cands)
     if whole:
         a, b = 0, len(lines)
     ops = collections.Counter(l.split()[0] for l in lines[a:b] if not l.endswith(":"))
@@ -60,7 +65,7 @@ def mix(text, kernel, whole=False):
 
 
 def main():
-    """python tools/isa_mix.py [kernel[:whole] ...] [--out profiles/rNN_isa_mix.json]"""
+    """python tools/isa_mix.py [kernel[:whole|:inner] ...] [--out profiles/rNN_isa_mix.json]"""
     args = sys.argv[1:]
     out_path = None
     if "--out" in args:
@@ -72,7 +77,7 @@ def main():
     res = {}
     for k in kernels:
         name, _, mode = k.partition(":")
-        res[name] = mix(text, name, whole=(mode == "whole"))
+        res[name] = mix(text, name, whole=(mode == "whole"), inner=(mode == "inner"))
         print(json.dumps({x: res[name][x] for x in ("kernel", "valu_per_step", "multiplier_rate_class_per_step", "multiplier_rate_share", "multiplier_rate_class")}))
     if out_path:
         json.dump(res, open(out_path if os.path.isabs(out_path) else os.path.join(ROOT, out_path), "w"), indent=1)

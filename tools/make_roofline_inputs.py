@@ -5,14 +5,14 @@
 
 Inputs: the rocprofv3 --pmc passes of tools/profile_pmc.sh (one counter group per pass, no trace
 domains), the pinned-occupancy instruction-rate table of tools/ubench/occupancy, and the compiler's
-instruction mix (tools/isa_mix.py, run here).  The JSON carries the sha256 of the libzerocaf_hip.so the
-counters were taken on; bench.py drops every PMC-derived roofline field when it loads another build.
+instruction mix (tools/isa_mix.py, run here).  The JSON carries the sha256 of the kernel
+sources (dusk_zerocaf_amd.build.sources_sha256) the counters were taken on; bench.py drops every PMC-derived
+roofline field when the tree's sources differ.
 Per-unit figures: counter total over every dispatch of the workload's kernels / (calls x units per call).
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), the gfx950 correction MI355X_MICROARCH.md
 prescribes for wide coalesced reads (the guide calls other access widths uncalibrated: the 2x is an
 upper bound for the narrow gathers of the windowed core and the MSM)."""
 import csv
-import hashlib
 import json
 import os
 import re
@@ -25,7 +25,7 @@ LIB = os.path.join(ROOT, "dusk_zerocaf_amd", "libzerocaf_hip.so")
 CALLS = 3                                   # profile_pmc.sh: --warmup 1 --steps 2
 WORKLOADS = {
     # name: (units per call, algorithmic bytes per unit, dispatch filter, ISA-mix kernel)
-    "scalar_mul": (1 << 20, 360, lambda k: k.startswith("k_ed_scalar_mul"), "k_ed_scalar_mul"),
+    "scalar_mul": (1 << 20, 360, lambda k: k.startswith(("k_ed_scalar_mul", "k_sm_cost")), "k_ed_scalar_mul_pw"),
     "ristretto": (1 << 22, 104, lambda k: k.startswith("k_ris_roundtrip_mul_fast"), "k_ris_roundtrip_mul_fast"),
     "msm": (1 << 21, 200, lambda k: not k.startswith(("k_ed_mul_base", "k_base_table_build")), "k_msm_runs"),
 }
@@ -65,8 +65,10 @@ def main():
     os.makedirs(raw, exist_ok=True)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_mix
+    sys.path.insert(0, ROOT)
+    from dusk_zerocaf_amd import build as zbuild
     text = isa_mix.compile_asm()
-    mixes = {k: isa_mix.mix(text, k) for k in sorted({w[3] for w in WORKLOADS.values()} | {"k_ed_scalar_mul_fast"})}
+    mixes = {k: isa_mix.mix(text, k, inner=k.endswith("_pw")) for k in sorted({w[3] for w in WORKLOADS.values()} | {"k_ed_scalar_mul_fast"})}
     json.dump(mixes, open(os.path.join(prof, tag + "_isa_mix.json"), "w"), indent=1)
 
     occ = parse_occupancy(occ_path)
@@ -86,12 +88,12 @@ def main():
         "v_add_u32_T_lane_ops_per_s": max(r["T_lane_ops_per_s"] for r in occ["v_add_u32"].values()),
     }
 
-    out = {"source": "profiles/%s_pmc_summary.md" % tag, "lib_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest(),
+    out = {"source": "profiles/%s_pmc_summary.md" % tag, "kernel_sources_sha256": zbuild.sources_sha256(),
            "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
            "ubench": ubench, "kernels": {}}
     md = ["# Round %s: rocprofv3 --pmc passes (tools/profile_pmc.sh; one counter group per pass, no trace domains)" % tag[1:].lstrip("0"), "",
-          "Raw CSVs: profiles/%s_raw/.  Library sha256 %s.  Every figure is the total over all dispatches of the workload's kernels in "
-          "%d calls (1 warm-up + 2 timed), divided by calls x units." % (tag, out["lib_sha256"][:16], CALLS), ""]
+          "Raw CSVs: profiles/%s_raw/.  Kernel sources sha256 %s.  Every figure is the total over all dispatches of the workload's kernels in "
+          "%d calls (1 warm-up + 2 timed), divided by calls x units." % (tag, out["kernel_sources_sha256"][:16], CALLS), ""]
     for wl, (units, alg, keep, mixk) in WORKLOADS.items():
         c, per_kernel = {}, {}
         for grp in ("sq1", "sq2", "fetch", "write"):
