@@ -794,6 +794,37 @@ def test_device_resident_buffers(eng, oracle):
         eng.use_own_stream()
 
 
+def test_device_resident_windowed_core_chunks(eng, oracle):
+    """Device-resident batches larger than one launch of the windowed core (786 432 lanes of table
+    scratch) go chunk by chunk, alternating between the launch stream and a forked stream.  2^21 + 1000
+    units = three chunks with a ragged tail: the fused Ristretto round trip (bytes + ok mask, ~1 %
+    undecodable inputs) and ZC_SCALAR_MUL_FAST (as encodings) against the oracle on slices from every
+    chunk and across both chunk boundaries; repeated calls reuse the scratch."""
+    import torch
+    import dusk_zerocaf_amd as z
+    n = (1 << 21) + 1000
+    small = V.base_multiples(oracle, 1 << 11, V.SEED + 160)
+    enc = np.tile(oracle.ris_compress(small), (n // (1 << 11) + 1, 1))[:n].copy()
+    enc[::97, 31] |= 0x80
+    K = V.rand_scalars_np(n, V.SEED + 161, bits=252)
+    _edge_scalars(K)
+    d_enc, dK = torch.from_numpy(enc).cuda(), torch.from_numpy(K.view(np.int64)).cuda()
+    chunk = 786432
+    sel = np.r_[0:300, chunk - 300:chunk + 300, 2 * chunk - 300:2 * chunk + 300, n - 300:n]
+    wout, wok = oracle.mt(oracle.ris_roundtrip_mul, enc[sel], K[sel])
+    for _ in range(2):
+        out, ok = eng.ris_roundtrip_mul(d_enc, dK)
+        torch.cuda.synchronize()
+        assert eq(out.cpu().numpy()[sel], wout) and eq(ok.cpu().numpy()[sel], wok)
+    assert (wok == 0).sum() > 5
+    P = np.tile(small, (n // (1 << 11) + 1, 1))[:n].copy()
+    dP = torch.from_numpy(P.view(np.int64)).cuda()
+    Q = eng.ed_scalar_mul(dP, dK, flags=z.FAST)
+    torch.cuda.synchronize()
+    want = oracle.mt(oracle.ed_scalar_mul, P[sel], K[sel])
+    assert eq(oracle.ed_compress(Q.cpu().numpy().view(np.uint64)[sel])[0], oracle.ed_compress(want)[0])
+
+
 def test_host_batches_move_in_chunks(eng, oracle, monkeypatch):
     """Host (numpy) batches of the scalar-mul family pass through the device in chunks that
     overlap copies with kernels; any chunking must give the bytes of the one-piece run, with

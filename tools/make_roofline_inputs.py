@@ -50,11 +50,11 @@ def totals(path, keep):
 def parse_occupancy(path):
     rows = {}
     for l in open(path):
-        m = re.match(r"^(.{26})\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", l)
+        m = re.match(r"^(.{28})\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", l)
         if m:
             rows.setdefault(m.group(1).strip(), {})[int(m.group(2))] = {
                 "ms": float(m.group(3)), "cyc_per_slot_median_wave": float(m.group(4)), "spread": float(m.group(5)),
-                "ghz": float(m.group(6)), "T_lane_ops_per_s": float(m.group(8))}
+                "rounds": float(m.group(6)), "ghz": float(m.group(7)), "T_lane_ops_per_s": float(m.group(9))}
     return rows
 
 

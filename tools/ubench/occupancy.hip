@@ -6,7 +6,8 @@
 // 1.7x one wave's own run time).  Every wave stamps s_memtime (shader cycles) and s_memrealtime
 // (100 MHz) around its loop.  Printed per (instruction mix, k):
 //   cyc/slot   shader cycles per wave-instruction per SIMD = wave cycles / (instructions x k), median wave
-//   spread     slowest wave / median wave (1.00 = every wave really shared its SIMD with k - 1 others)
+//   spread     slowest wave / median wave (older waves win the issue arbitration)
+//   rounds     launch time / slowest wave's own run time (1.0 = all k workgroups per CU resident at once)
 //   GHz        effective shader clock of the median wave during the loop
 //   T lane/s   whole-chip lane-operations per second from the HIP-event time of the launch
 // Mixes: "A+nB" = one A followed by n B, independent chains, to see whether 32-bit ALU ops hide
@@ -44,6 +45,12 @@ template <int MIX> __device__ __forceinline__ void body(u64 (&acc)[CH], u32 (&x)
         if (MIX == 8) {   // dependent chain of mads on ONE accumulator (the column-ordered multiplier's shape)
             asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
         }
+        if (MIX == 9) {   // TWO dependent chains, interleaved (two column-ordered multiplications side by side)
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c & 1]) : "v"(a), "v"(b) : "vcc");
+        }
+        if (MIX == 10) {  // one dependent chain with the hazard s_nop hipcc puts between dependent mads
+            asm volatile("s_nop 0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
+        }
     }
 }
 template <int MIX> __global__ __launch_bounds__(256) void k(u32* out, int iters, u32 seed, u64* stamps)
@@ -77,19 +84,19 @@ int main(int argc, char** argv)
     std::vector<Ent> ents = {
         {"v_mad_u64_u32", k<0>, 1, 1}, {"v_fma_f32", k<1>, 1, 0}, {"v_add_u32", k<2>, 1, 0}, {"v_mul_lo_u32", k<3>, 1, 0},
         {"v_lshrrev_b64", k<4>, 1, 0}, {"4 mad + 1 add", k<5>, 1.25, 1}, {"1 mad + 1 add", k<6>, 2, 1}, {"1 mad + 2 alu", k<7>, 3, 1},
-        {"mad, one dependent chain", k<8>, 1, 1}};
+        {"mad, one dependent chain", k<8>, 1, 1}, {"mad, two chains interleaved", k<9>, 1, 1}, {"s_nop + dependent mad", k<10>, 1, 1}};
     const int max_waves = cus * 8 * 4;
     u32* out; hipMalloc(&out, (size_t)max_waves * 64 * 4);
     u64* stamps; hipMalloc(&stamps, (size_t)max_waves * 16);
     std::vector<u64> h(2 * (size_t)max_waves);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("%-26s %6s %8s %9s %7s %6s %9s %12s\n", "mix", "w/SIMD", "ms", "cyc/slot", "spread", "GHz", "cyc/mad", "T lane/s");
+    printf("%-28s %6s %8s %9s %7s %7s %6s %9s %12s\n", "mix", "w/SIMD", "ms", "cyc/slot", "spread", "rounds", "GHz", "cyc/mad", "T lane/s");
     for (auto& e : ents) {
         hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
         for (int kk : {1, 2, 3, 4, 5, 6, 8}) {
-            // k workgroups fit, k + 1 do not:  lds_cu / (k + 1) < bytes <= lds_cu / k
-            size_t bytes = (lds_cu / kk) / 1024 * 1024;
-            if (kk == 8) bytes = 19 * 1024;                        // 8 x 19 = 152 KB; the wave slots cap at 8 anyway
+            // k workgroups fit with room to spare for the allocation granularity, k + 1 do not
+            static const int kb[9] = {0, 96, 64, 48, 36, 30, 25, 0, 19};
+            const size_t bytes = (size_t)kb[kk] * 1024;
             const int grid = cus * kk;
             int iters = 1024;
             auto launch = [&](int it) { hipLaunchKernelGGL(e.fn, dim3(grid), dim3(256), bytes, 0, out, it, 12345u, stamps); };
@@ -112,7 +119,9 @@ int main(int argc, char** argv)
             const double cyc_slot = med / (groups * e.slots * kk);
             const double lane = e.mads > 0 ? (double)waves * groups * e.mads * 64 / (ms * 1e-3) / 1e12
                                            : (double)waves * groups * e.slots * 64 / (ms * 1e-3) / 1e12;
-            printf("%-26s %6d %8.3f %9.3f %7.3f %6.3f %9.3f %12.2f\n", e.name, kk, ms, cyc_slot, cyc[waves - 1] / med, ghz[waves / 2],
+            // launch time over the slowest wave's own run time: 1.0 = every workgroup was resident from the start
+            const double rounds = ms * 1e-3 / (cyc[waves - 1] / (ghz[waves / 2] * 1e9));
+            printf("%-28s %6d %8.3f %9.3f %7.3f %7.2f %6.3f %9.3f %12.2f\n", e.name, kk, ms, cyc_slot, cyc[waves - 1] / med, rounds, ghz[waves / 2],
                    e.mads > 0 ? med / (groups * e.mads * kk) : 0.0, lane);
         }
     }
