@@ -149,7 +149,11 @@ ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 
             raw_store_zero(dst + MSM_RAW_WORDS);
         }
     }
+#ifndef ZC_MSM_PROBE_NOFLUSH     // timing probe only: the sums are dropped
     pt_store_raw(dst, sum);
+#else
+    if (sum.X.v[0] == 0x12345678u && sum.Y.v[3] == 0x1357u) pt_store_raw(dst, sum);
+#endif
 }
 
 // Level 0 of the segmented reduction (see the file header): the sorted (key, point index | sign << 31)
@@ -163,14 +167,18 @@ ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 
 #ifndef ZC_MSM_WAVES
 #define ZC_MSM_WAVES 4         // resident waves per SIMD the bucket-sum kernel is compiled for (A/B knob)
 #endif
-extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
+#ifndef ZC_MSM_RUN_BLOCK
+#define ZC_MSM_RUN_BLOCK 256   // threads per workgroup of k_msm_runs (its waves never synchronise: A/B knob)
+#endif
+constexpr int MSM_RUN_BLOCK = ZC_MSM_RUN_BLOCK;
+extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T, u32 nbuckets,
                 u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
 {
-    __shared__ uint4 stage[8 * ZC_BLOCK];
+    __shared__ uint4 stage[8 * MSM_RUN_BLOCK];
     const int lane = threadIdx.x & 63;
     uint4* base = stage + (threadIdx.x >> 6) * (8 * 64);
-    const u32 j = blockIdx.x * ZC_BLOCK + threadIdx.x;
+    const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
     const u64 lo64 = (u64)j * T;
     if (lo64 >= len) return;
     const u32 lo = (u32)lo64;
@@ -183,7 +191,11 @@ void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T
     const u32 prev_key = lo > 0 ? keys[lo - 1] : none;
     const u32 next_key = hi < len ? keys[hi] : none;
     auto fetch = [&](u32 v) {
+#ifdef ZC_MSM_PROBE_NOGATHER   // timing probe only (wrong sums): every gather hits one of 256 cache-resident records
+        const uint4* src = reinterpret_cast<const uint4*>(recs + 32 * (size_t)(v & 0xFFu));
+#else
         const uint4* src = reinterpret_cast<const uint4*>(recs + 32 * (size_t)(v & 0x7FFFFFFFu));
+#endif
 #pragma unroll
         for (int q = 0; q < 8; q++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q),

@@ -513,6 +513,14 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     if (cnt > 0x7FFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 31-bit point indices");
     const int c = msm_window_bits(cnt);
     const int W = (zc::MSM_SCALAR_BITS + c - 1) / c;      // any 260-bit pattern + the recoding carry
+    if (getenv("ZC_DEBUG_OCCUPANCY")) {
+        int a = 0, b = 0, e = 0, f = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, zc::k_msm_runs, zc::ZC_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, zc::k_ed_scalar_mul_pw, zc::ZC_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, zc::k_ris_roundtrip_mul_fast, zc::ZC_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, zc::k_msm_segments, zc::ZC_BLOCK, 0);
+        fprintf(stderr, "occupancy (workgroups of 256 per CU): k_msm_runs %d, k_ed_scalar_mul_pw %d, k_ris_roundtrip_mul_fast %d, k_msm_segments %d\n", a, b, e, f);
+    }
     const size_t m = cnt * (size_t)W;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
     const size_t nb = (size_t)W << (c - 1);               // buckets (digit magnitudes 1 .. 2^(c-1) per window)
@@ -578,7 +586,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 zc::u32* nk = ekeys[level & 1];
                 zc::u32* nr = erecs[level & 1];
                 if (level == 0)
-                    hipLaunchKernelGGL(zc::k_msm_runs, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, (const zc::u32*)vb.current(), (const zc::u32*)cached,
+                    hipLaunchKernelGGL(zc::k_msm_runs, dim3((unsigned)((nl + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), 0, D.s(), lk, (const zc::u32*)vb.current(), (const zc::u32*)cached,
                                        (zc::u32)len, (zc::u32)t, (zc::u32)nb, buckets, present, nk, nr);
                 else
                     hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
