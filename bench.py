@@ -26,7 +26,8 @@ roofline: the scalar-mul / Ristretto / MSM kernels are bound by the integer mult
 `frac_useful` counts only the multiplications the reference's formula sequence needs (computed from
 the actual scalars of this run: sum of bitlen - 1 + popcount formula evaluations x 9 multiplications
 x 135 v_mad_u64_u32) -- no profile input at all.  The PMC-derived fields are dropped (null, with a
-note) when the profile was taken on other kernel sources than the tree's (sha256 of csrc/ + the header).  The HBM view
+note) when the profile was taken on other kernel sources than the loaded library was built from (sha256 of
+csrc/ + the header, embedded in zc_version()).  The HBM view
 (algorithmic bytes / time vs 8 TB/s, PMC traffic) is kept under `hbm`.  fe_mul is HBM-bound: `bound` = "hbm".
 """
 from __future__ import annotations
@@ -120,17 +121,20 @@ def roofline_inputs(lib_path):
     if not os.path.exists(path):
         return None, "profiles/roofline_inputs.json missing"
     inp = json.load(open(path))
-    from dusk_zerocaf_amd import build as zbuild
-    sha = zbuild.sources_sha256()
-    if os.environ.get("ZC_LIB_PATH") or zbuild.stale():
-        return inp, "the loaded library is not a build of the kernel sources in the tree: PMC-derived fields dropped"
-    if inp.get("kernel_sources_sha256") != sha:
-        return inp, "profile taken on other kernel sources (sha256 %s..., tree %s...): PMC-derived fields dropped" % (
-            str(inp.get("kernel_sources_sha256"))[:12], sha[:12])
+    import dusk_zerocaf_amd as z
+    built_from = z.load().zc_version().decode().rsplit("src:", 1)[-1]      # hash of the sources the loaded library was built from
+    if inp.get("kernel_sources_sha256") != built_from:
+        return inp, "profile taken on other kernel sources (sha256 %s...) than the loaded library was built from (%s...): PMC-derived fields dropped" % (
+            str(inp.get("kernel_sources_sha256"))[:12], built_from[:12])
     return inp, None
 
 
 def main():
+    # RCCL and the HIP runtime print banners on fd 1 ("RCCL version : ...") when a communicator is created;
+    # the contract is ONE JSON line on stdout, so everything else written to fd 1 goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -341,7 +345,7 @@ def main():
         "cpu_baseline": cpu,
         "parity_spot_check": checked,
     }
-    print(json.dumps(line), flush=True)
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -41,8 +41,8 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB,
+           '-DZC_SRC_HASH="%s"' % sources_sha256()] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -55,8 +55,8 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
     out_dir = os.path.join(os.path.dirname(HERE), "build", "variants")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
-          ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out,
+           '-DZC_SRC_HASH="variant:%s"' % name] + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

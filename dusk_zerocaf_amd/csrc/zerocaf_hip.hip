@@ -694,7 +694,12 @@ const uint64_t IDENT_POINT[20] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0
 // =============================================================================== C ABI
 extern "C" {
 
-const char* zc_version(void) { return "zerocaf_hip 0.1 (gfx950, radix-2^29 Montgomery R=2^261)"; }
+// ZC_SRC_HASH: sha256 of the kernel sources + the ABI header, passed in by dusk_zerocaf_amd/build.py;
+// it ties a profile (profiles/roofline_inputs.json) to the build it was taken on
+#ifndef ZC_SRC_HASH
+#define ZC_SRC_HASH "unknown"
+#endif
+const char* zc_version(void) { return "zerocaf_hip 0.2 (gfx950, radix-2^29 Montgomery R=2^261) src:" ZC_SRC_HASH; }
 const char* zc_last_error(void) { return g_last_error.c_str(); }
 
 int zc_device_count(void)

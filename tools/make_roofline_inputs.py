@@ -88,7 +88,12 @@ def main():
         "v_add_u32_T_lane_ops_per_s": max(r["T_lane_ops_per_s"] for r in occ["v_add_u32"].values()),
     }
 
-    out = {"source": "profiles/%s_pmc_summary.md" % tag, "kernel_sources_sha256": zbuild.sources_sha256(),
+    # the hash of the sources the profiled library was built from (zc_version(), recorded by profile_pmc.sh)
+    ver = os.path.join(pmc_dir, "lib_version.txt")
+    src_hash = open(ver).read().strip().rsplit("src:", 1)[-1] if os.path.exists(ver) else zbuild.sources_sha256()
+    if src_hash != zbuild.sources_sha256():
+        print("WARNING: the profile was taken on other kernel sources (%s...) than the tree's (%s...)" % (src_hash[:12], zbuild.sources_sha256()[:12]))
+    out = {"source": "profiles/%s_pmc_summary.md" % tag, "kernel_sources_sha256": src_hash,
            "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
            "ubench": ubench, "kernels": {}}
     md = ["# Round %s: rocprofv3 --pmc passes (tools/profile_pmc.sh; one counter group per pass, no trace domains)" % tag[1:].lstrip("0"), "",
