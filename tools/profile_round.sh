@@ -9,15 +9,18 @@
 # domains), as MI355X_MICROARCH.md prescribes.
 set -u
 TAG=${1:-r02}
+MODE=${2:-all}            # "bench": only the bench.py lines (after profiles/roofline_inputs.json was regenerated)
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT/tmp"
+if [ "$MODE" != bench ]; then rm -rf "$OUT"; fi
+mkdir -p "$OUT/tmp"
 cd /tmp; export TMPDIR=/tmp
 PY="python $REPO/bench.py --cpu-sample 0"
 
 flatten() { find "$OUT/tmp" -name '*.csv' -exec mv {} "$OUT/" \; ; rm -rf "$OUT/tmp"/*; }
 kt() { local name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tmp" -o "kt_$name" -- $PY "$@" > "$OUT/kt_$name.log" 2>&1; flatten; }
 
+if [ "$MODE" != bench ]; then
 kt scalar_mul --steps 5 --warmup 3
 kt ristretto --workload ristretto --units 4194304 --steps 5 --warmup 1
 kt msm_2p21 --workload msm --units 2097152 --steps 5 --warmup 1
@@ -27,6 +30,8 @@ kt fe_mul --workload fe_mul --units 16777216 --steps 20 --warmup 30
 cd "$REPO"
 tools/profile_pmc.sh "$TAG" > "$OUT/pmc.log" 2>&1
 [ -x tools/ubench/occupancy ] && timeout 300 tools/ubench/occupancy 20 > "$OUT/occupancy.txt" 2>&1
+fi
+cd "$REPO"
 python bench.py > "$OUT/bench_scalar_mul.json" 2> "$OUT/bench_scalar_mul.log"
 python bench.py --scalar-bits 249 --cpu-sample 0 > "$OUT/bench_scalar_mul_s249.json" 2>/dev/null
 python bench.py --units 16777216 --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/bench_scalar_mul_2p24.json" 2>/dev/null
