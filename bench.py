@@ -314,7 +314,12 @@ def main():
             raise SystemExit("PARITY FAILURE: GPU result differs from the oracle")
         what = {"scalar_mul": "zr_ed_scalar_mul (double_and_add)", "fe_mul": "zr_fe_mul", "ristretto": "zr_ris_roundtrip_mul (decompress, double_and_add, compress)",
                 "msm": "zr_msm_naive (sum of double_and_add results with the unified add)"}[wl]
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            model = "unknown CPU"
         cpu = None if not baseline_leg else {"value": round(v, 1), "unit": W["unit"], "cores": cores, "kind": "port",
+               "value_per_core": round(v / cores, 1), "cpu_model": model,
                "sample": "%d units from the head of the same seeded workload, %d threads, %.1f s wall (%.0f s of CPU work): %s; C "
                          "restatement of zerocaf's u64 backend (oracle/zc_ref.c, gcc -O3), not the Rust binary"
                          % (total, cores, secs, secs * cores, what)}
