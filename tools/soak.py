@@ -55,4 +55,25 @@ rng = np.random.default_rng(seed)
 raw = rng.integers(0, 256, size=(1 << 15, 32), dtype=np.uint8); raw[:, 31] &= 0x1F
 d, ok = eng.ris_decompress(raw); wd, wok = par(zc_ref.ris_decompress, len(raw), raw)
 assert np.array_equal(d, wd) and np.array_equal(ok, wok)
-print("soak seed %d ok in %.1f s" % (seed, time.time() - t0))
+# persistent-wave strict path (>= 2^17 elements): ragged size, raw limb patterns up to 2^260 mixed in
+nb = (1 << 17) + int(rng.integers(1, 1 << 16))
+Pb = np.tile(P, (nb // n + 1, 1))[:nb].copy()
+Kb = V.rand_scalars_np(nb, seed * 100 + 31, bits=252)
+wild = rng.choice(nb, size=nb // 50, replace=False)
+Kb[wild] = rng.integers(0, 1 << 52, size=(len(wild), 5), dtype=np.uint64)
+Kb[rng.choice(nb, size=64, replace=False)] = 0
+Kb[wild[:200], :4] = 0                                           # low 208 bits clear: the early-stopping loop cases
+assert np.array_equal(eng.ed_scalar_mul(Pb, Kb), par(zc_ref.ed_scalar_mul, nb, Pb, Kb)), "persistent-wave scalar_mul"
+# bucket-method MSM against the oracle's sum of double_and_add results, random size and scalar width
+nm = int(rng.integers(1 << 12, 1 << 17))
+bits = int(rng.choice([64, 128, 249, 252]))
+Km = V.rand_scalars_np(nm, seed * 100 + 32, bits=max(bits, 249))
+if bits < 249:                                                   # short scalars: only the low `bits` bits
+    for j in range(5):
+        keep = min(52, max(0, bits - 52 * j))
+        Km[:, j] &= np.uint64((1 << keep) - 1)
+Km[rng.choice(nm, size=nm // 100 + 1, replace=False)] = rng.integers(0, 1 << 52, size=(nm // 100 + 1, 5), dtype=np.uint64)
+Pm = np.tile(P, (nm // n + 1, 1))[:nm].copy()
+got, want = eng.msm(Pm, Km), zc_ref.msm_naive_mt(Pm, Km)
+assert zc_ref.ed_eq(got, want)[0] == 1 and np.array_equal(zc_ref.ed_compress(got)[0], zc_ref.ed_compress(want)[0]), "msm n=%d bits=%d" % (nm, bits)
+print("soak seed %d ok in %.1f s (persistent-wave n=%d, msm n=%d bits=%d)" % (seed, time.time() - t0, nb, nm, bits))
