@@ -342,6 +342,15 @@ ZC_DI pt pt_double_quad(const pt& p, int role)
 ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c)
 {
     const int role = threadIdx.x & 3;
+    // leading windows whose sum is the literal identity (0 : y : y : 0) -- the windows above the longest
+    // scalar of the batch -- need no doublings: Horner's rule starts at the first non-trivial one
+    for (; W > 1; W--) {
+        const u64* s = windows + 20 * (size_t)(W - 1);
+        u64 nz = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) nz |= s[j] | s[15 + j] | (s[5 + j] ^ s[10 + j]);
+        if (nz) break;
+    }
     pt Q = pt_load(windows + 20 * (size_t)(W - 1));
     for (int w = W - 2; w >= 0; w--) {
         for (int i = 0; i < c; i++) Q = pt_double_quad(Q, role);

@@ -478,13 +478,14 @@ struct Carver {
 
 // Window width: signed digits put 2^(c-1) buckets in a window; c = log2(n) - 4 keeps about 32
 // points per bucket, where the bucket reduction (~3.7 additions per bucket) stays well below the
-// bucket sums (1 addition per point and window); measured flat within 3 % for c +- 1 at 2^20, 2^21 and
-// for c = 18..21 at 2^24.  ZC_MSM_WINDOW=c overrides (tests, tuning).
+// bucket sums (1 addition per point and window); measured flat within 3 % for c +- 1 up to 2^18 and at 2^21,
+// and for c = 18..21 at 2^24 (tools/quick_bench.py msmsweep).  ZC_MSM_WINDOW=c overrides (tests, tuning).
 int msm_window_bits(size_t cnt)
 {
     int c = 0;
     while (((size_t)1 << (c + 1)) <= cnt) c++;
     c -= 4;
+    if (c == 15 || c == 16) c = 17;                       // 2^19, 2^20 pairs: 16 windows of 17 bits beat 18 of 15 / 17 of 16 (measured -4 %)
     if (c < zc::MSM_MIN_C) c = zc::MSM_MIN_C;
     if (c > 19) c = 19;                                   // beyond: flat in time (measured to 2^24), bucket memory doubles per step
     if (const char* e = getenv("ZC_MSM_WINDOW")) {

@@ -68,8 +68,8 @@ def main():
         if "msm%d" % lg in what:
             P, _, K = inputs(lg)
             out["msm_2p%d_ms" % lg] = timed(lambda: eng.msm(P, K), reps=3, warm=1)
-    if "msmsweep" in what:
-        for lg in (20, 21, 24):
+    if "msmsweep" in what or "msmsweep_small" in what:
+        for lg in ((20, 21, 24) if "msmsweep" in what else (13, 14, 16, 18, 19)):
             P, _, K = inputs(lg)
             for c in range(lg - 6, lg - 1):
                 if 5 <= c <= 22:
