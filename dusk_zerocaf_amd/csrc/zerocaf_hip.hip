@@ -529,11 +529,12 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     int keybits = c - 1;
     while (((size_t)1 << keybits) <= nb) keybits++;       // the sentinel key nb must sort last
 
-    // run length of the segmented reduction: 32 entries per lane, fewer when the list is short
-    // (keep >= 64 K lanes busy); ZC_MSM_RUN overrides
-    // Longer runs leave fewer edges (2 per run) for the deeper levels; 2^19 lanes keep the chip full.
-    int T = (int)std::min<size_t>(128, std::max<size_t>(8, m >> 19));
-    int TE = 16;                                          // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
+    // run length of the segmented reduction: 128 entries per lane, fewer when the list is short (keep
+    // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
+    // levels.  Measured (tools/quick_bench.py, ZC_MSM_RUN / ZC_MSM_RUN_EDGES): 2^20 pairs T = 32 / 128 / 256:
+    // 2.90 / 2.83 / 3.12 ms; 2^21: 4.67 / 4.48 / 4.52; edge runs of 8 / 16 / 32: 2^21 4.44 / 4.53 / 4.63 ms.
+    int T = (int)std::min<size_t>(128, std::max<size_t>(8, m >> 17));
+    int TE = 8;                                           // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
     if (const char* e = getenv("ZC_MSM_RUN")) {
         const int f = atoi(e);
         if (f >= 4 && f <= 4096) T = f;                   // T >= 4: every level shortens the list (2 ceil(len / T) < len)
