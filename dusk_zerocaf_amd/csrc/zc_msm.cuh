@@ -40,7 +40,11 @@
 
 namespace zc {
 
-constexpr int MSM_SEG = 16;   // buckets per reduction segment
+// Buckets per reduction segment (one lane each): short segments keep enough lanes busy when there are few
+// buckets, long ones spend fewer doublings' worth of work on the (first mod 2^(c-1)) * acc products.
+// Measured (2^16 / 2^18 / 2^20 / 2^21 / 2^24 pairs, ms): 8: 1.10 / 1.50 / 2.81 / 4.53 / 24.75,
+// 16: 1.17 / 1.55 / 2.77 / 4.42 / 24.40, 32: 1.30 / 1.68 / 2.93 / 4.56 / 24.05.
+inline int msm_segment_buckets(size_t nbuckets) { return nbuckets <= ((size_t)1 << 18) ? 8 : nbuckets >= ((size_t)1 << 21) ? 32 : 16; }
 constexpr int MSM_SCALAR_BITS = 261;   // 260-bit limb patterns + the carry of the signed recoding
 constexpr int MSM_MIN_C = 5, MSM_MAX_C = 22;
 
@@ -267,18 +271,18 @@ ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T
     }
 }
 
-// One lane per segment of MSM_SEG consecutive buckets [first, first + SEG) of one window (bucket
+// One lane per segment of `seg` consecutive buckets [first, first + SEG) of one window (bucket
 // index b of a window holds the digit magnitude b + 1):
 //   acc = sum_j B_{first+j},  sum = sum_j (j + 1) B_{first+j}   (running sums from the top bucket down)
 // so that  sum_j (first' + j + 1) B_{first+j} = sum + first' * acc  with first' = first mod 2^(c-1).
 // Emits sum, acc and the scalar first'.
-ZC_KERNEL void k_msm_segments(const u32* buckets_raw, const uint8_t* present, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c)
+ZC_KERNEL void k_msm_segments(const u32* buckets_raw, const uint8_t* present, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c, int seg)
 {
     const size_t s = gid();
     if (s >= nseg_total) return;
-    const size_t first = s * MSM_SEG;                     // global bucket index of the segment start
+    const size_t first = s * (size_t)seg;                 // global bucket index of the segment start
     pt acc = pt_identity(), sum = pt_identity();
-    for (int j = MSM_SEG - 1; j >= 0; j--) {
+    for (int j = seg - 1; j >= 0; j--) {
         pt b = pt_identity();
         if (present[first + j]) b = pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j));
         acc = pt_add<true>(acc, b);

@@ -525,7 +525,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     const size_t m = cnt * (size_t)W;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
     const size_t nb = (size_t)W << (c - 1);               // buckets (digit magnitudes 1 .. 2^(c-1) per window)
-    const size_t nseg = nb / zc::MSM_SEG;
+    const int seg = zc::msm_segment_buckets(nb);
+    const size_t nseg = nb / (size_t)seg;
     int keybits = c - 1;
     while (((size_t)1 << keybits) <= nb) keybits++;       // the sentinel key nb must sort last
 
@@ -600,7 +601,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 len = 2 * nl;
             }
         }
-        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)buckets, (const uint8_t*)present, seg_sum, seg_acc, seg_k, nseg, c);
+        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)buckets, (const uint8_t*)present, seg_sum, seg_acc, seg_k, nseg, c, seg);
         // seg_acc <- (first mod 2^(c-1)) * seg_acc ; seg_sum <- seg_sum + seg_acc
         hipLaunchKernelGGL(strict_kernel_for(nseg), dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
                            seg_acc, (const zc::u32*)nullptr, nseg);
