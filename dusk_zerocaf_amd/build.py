@@ -38,7 +38,24 @@ def stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+UBENCH_LIB = os.path.join(HERE, "libzc_ubench.so")
+
+
+def build_ubench(force: bool = False, verbose: bool = False) -> str:
+    """libzc_ubench.so: the live instruction-rate measurement bench.py prices its roofline against
+    (a measurement aid, not part of the product library)."""
+    src = os.path.join(CSRC, "zc_ubench.hip")
+    if not force and os.path.exists(UBENCH_LIB) and os.path.getmtime(UBENCH_LIB) >= os.path.getmtime(src):
+        return UBENCH_LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", UBENCH_LIB, src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return UBENCH_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_ubench(force, verbose)
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB,
