@@ -679,8 +679,15 @@ ZC_DI int scalar_digits16(int8_t* __restrict__ dig, int stride, const u64 (&l)[5
     return top;
 }
 
-template <bool ILP>
-ZC_DI pt fast_window_loop(const u32* __restrict__ table, const int8_t* __restrict__ dig, int stride, int top)
+// Where a lane's table lives.  table_ptr: a plain per-lane pointer (host emulation).  The kernels pass a
+// wave-uniform slot base instead (zc_kernels.cuh: ring_table) and form the lane's offset at every access, so
+// that no per-lane pointer stays live in vector registers across the window loop.
+struct table_ptr {
+    u32* p;
+    ZC_DI u32* entry(int j) const { return p + 32 * j; }
+};
+template <bool ILP, class TABLE>
+ZC_DI pt fast_window_loop(const TABLE table, const int8_t* __restrict__ dig, int stride, int top)
 {
     pt Q = pt_identity();
     for (int i = top; i >= 0; i--) {
@@ -693,7 +700,7 @@ ZC_DI pt fast_window_loop(const u32* __restrict__ table, const int8_t* __restric
         const int d = dig[i * stride];
         const int mag = d < 0 ? -d : d;
         niels c = niels_identity();
-        if (mag != 0) c = niels_load(table + 32 * (mag - 1));
+        if (mag != 0) c = niels_load(table.entry(mag - 1));
         Q = pt_add_cached<ILP>(Q, niels_cond_neg(d < 0, c));
     }
     return Q;
@@ -703,20 +710,21 @@ ZC_DI pt fast_window_loop(const u32* __restrict__ table, const int8_t* __restric
 // every lane of a wave runs the same schedule from window `top` (wave-uniform) down to 0.
 // NOT the reference's formula sequence: the result equals double_and_add's as a group element
 // (identical affine coordinates / encodings), its (X:Y:Z:T) limbs differ by a projective factor.
-ZC_DI pt scalar_mul_fast(const pt& P, u32* __restrict__ table, const int8_t* __restrict__ dig, int stride, int top)
+template <class TABLE>
+ZC_DI pt scalar_mul_fast(const pt& P, const TABLE table, const int8_t* __restrict__ dig, int stride, int top)
 {
     // table[j] = (j + 1) P, cached form:
     // one doubling, then a chain of cached additions of P.  (Two live points instead of the four a
     // doubling tree keeps: the build costs the same 55 multiplications and no longer forces spills.)
     {
         const niels c1 = niels_from_pt(P);
-        niels_store(table, c1);
+        niels_store(table.entry(0), c1);
         pt q = pt_double_fast<true>(P);
-        niels_store(table + 32, niels_from_pt(q));
+        niels_store(table.entry(1), niels_from_pt(q));
 #pragma unroll 1
         for (int j = 2; j < 8; j++) {
             q = pt_add_cached(q, c1);
-            niels_store(table + 32 * j, niels_from_pt(q));
+            niels_store(table.entry(j), niels_from_pt(q));
         }
     }
     // small launches (one wave per SIMD) take the independent-chain multiplier, like the strict kernel

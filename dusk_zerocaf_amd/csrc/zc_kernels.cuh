@@ -604,17 +604,89 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 // line per entry).  ~0.63x the multiplier work of the reference's formula sequence and no SIMT
 // divergence at all.  The result is the same group element as double_and_add's (identical
 // encodings); only its projective (X:Y:Z:T) representative differs.
-// `table`: 1 KB of scratch per lane of the launch (8 cached multiples, one cache line each).  The
-// host bounds a launch to FAST_CHUNK_LANES lanes and walks larger batches chunk by chunk on the
-// stream, so the scratch stays at 768 MB however large the batch is.  (A persistent grid -- 768
-// resident workgroups walking the tiles, 192 MB of tables -- was measured 14 % SLOWER, with the table
-// per slot or per tile alike: co-resident waves then start together, stay in lock step and stall on
-// their table loads together; short-lived workgroups drift apart and cover each other.)
-ZC_KERNEL_3W void k_ed_scalar_mul_fast(const u64* p, const u64* k, u32 k_stride, u64* out, u32* table, u32 n)
+// `table`: the 8 cached multiples of a lane's point, 1 KB per lane (one cache line per entry), in global
+// scratch.  The scratch is a RING OF WAVE SLOTS (64 lanes x 1 KB) PER XCD, 256 MB in all however large the
+// batch: a wave takes the next ticket of the XCD it runs on (HW_REG_XCC_ID; one atomic per wave), which
+// names slot = ticket mod 512 and generation = ticket / 512, waits until the slot's previous holder has
+// released it (practically never: 384 waves of this kernel are resident per XCD, so the holder 512 tickets
+// back is long gone), builds and reads its table there and releases the slot right after its last table
+// read.  One launch covers the whole batch.  (Round 2 first bounded the scratch by walking the batch in
+// launches of 786432 lanes over two table areas on two streams: every launch boundary cost 0.45 ms,
+// 3.7 % at 2^22.  Slot reuse inside one launch costs nothing: 61.0 ms with the ring against 61.0 ms
+// with 4 GiB of per-lane scratch, 63.3 ms chunked, same box.)
+//   * every lane reads only the entries it wrote itself after acquiring the slot, so no data crosses
+//     waves through the table; the only inter-wave traffic is the ticket counter and the slot flags;
+//   * tickets and flags of one XCD live in cache lines no other XCD touches, holder and successor of a
+//     slot run on the same XCD by construction, flags are stored and polled with agent-scope accesses
+//     (`sc1`: past the L1 of the CU) -- the per-XCD L2 they meet in is coherent for its own CUs;
+//   * a holder never waits for a later ticket, so the waits cannot cycle; the spin is bounded anyway
+//     (trap after ~4 s, which surfaces as a HIP error at the next synchronisation).
+// (A persistent grid -- 768 resident workgroups walking the tiles, 192 MB of tables -- was measured
+// 14 % SLOWER: co-resident waves then start together, stay in lock step and stall on their table
+// loads together; short-lived workgroups drift apart and cover each other.  The ring keeps the
+// short-lived workgroups.)
+constexpr u32 RING_XCDS = 8;                      // HW_REG_XCC_ID is masked to this range
+constexpr u32 RING_SLOTS = 512;                   // wave slots per XCD
+constexpr u32 RING_TICKET_STRIDE = 32;            // one 128-byte line per XCD's ticket counter
+constexpr u32 RING_STATE_WORDS = RING_XCDS * RING_TICKET_STRIDE + RING_XCDS * RING_SLOTS;
+constexpr size_t RING_TABLE_BYTES = (size_t)RING_XCDS * RING_SLOTS * 64 * 1024;
+
+// The lane's number, computed afresh wherever it is asked for: `volatile` keeps the compiler from sharing
+// one v_mbcnt result between distant uses, which would pin a vector register across the whole kernel
+// (the windowed-core kernels have none to spare).
+ZC_DI u32 lane_id_fresh()
+{
+    u32 l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// A wave's slot: 64 KB starting at `base` (wave-uniform: scalar registers), lane l owns [l KB, (l + 1) KB).
+struct ring_table {
+    u32* base;
+    ZC_DI u32* entry(int j) const
+    {
+        return base + (lane_id_fresh() * 256u + 32u * (u32)j);
+    }
+};
+// returns the wave's slot.  What ring_release needs (the slot's flag word and the generation to
+// publish, 13 + 19 bits) is parked in one LDS word per wave: the windowed core between the two calls is
+// short of scalar registers as it is (their spills occupy vector registers).
+ZC_DI ring_table ring_acquire(u32* __restrict__ table, u32* __restrict__ state, u32* __restrict__ hold, u32 slots)
+{
+    u32 xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= RING_XCDS - 1;
+    const u32 lane = lane_id_fresh();
+    u32 t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(state + RING_TICKET_STRIDE * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const u32 slot = t % slots, gen = t / slots;          // slots <= RING_SLOTS (fewer only to exercise the waits in tests)
+    const u32 flag_word = RING_XCDS * RING_TICKET_STRIDE + xcc * RING_SLOTS + slot;
+    if (lane == 0) *hold = flag_word | ((gen + 1) << 13);
+    if (gen) {                                    // the flag counts the generations that have released the slot
+        u32 spins = 0;
+        for (;;) {
+            const u32 f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(state + flag_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (f >= gen) break;
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 22)) __builtin_trap();
+        }
+    }
+    return ring_table{table + (size_t)(xcc * RING_SLOTS + slot) * (64 * 256)};
+}
+ZC_DI void ring_release(u32* __restrict__ state, const u32* __restrict__ hold)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every table read of every lane has returned
+    if (lane_id_fresh() == 0) {
+        const u32 h = *hold;
+        __hip_atomic_store(state + (h & 0x1FFFu), h >> 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+ZC_KERNEL_3W void k_ed_scalar_mul_fast(const u64* p, const u64* k, u32 k_stride, u64* out, u32* table, u32* ring, u32 ring_slots, u32 n)
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
     const int tid = threadIdx.x;
-    const u32 i = blockIdx.x * ZC_BLOCK + tid;             // a launch is at most FAST_CHUNK_LANES elements
+    const u32 i = blockIdx.x * ZC_BLOCK + tid;
     const bool valid = i < n;
     const u32 ii = valid ? i : 0;
     u64 l[5];
@@ -622,17 +694,20 @@ ZC_KERNEL_3W void k_ed_scalar_mul_fast(const u64* p, const u64* k, u32 k_stride,
     int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
     top = wave_max_small(top);
-    const pt Q = scalar_mul_fast(pt_load(p + 20 * (size_t)ii), table + 256 * (size_t)i, sdig + tid, ZC_BLOCK, top);
+    __shared__ u32 hold[ZC_BLOCK / 64];
+    const ring_table mine = ring_acquire(table, ring, hold + (tid >> 6), ring_slots);
+    const pt Q = scalar_mul_fast(pt_load(p + 20 * (size_t)ii), mine, sdig + tid, ZC_BLOCK, top);
+    ring_release(ring, hold + (threadIdx.x >> 6));
     if (valid) pt_store(out + 20 * (size_t)i, Q);
 }
 // fused config-4 path on the fast core: the boundary is bytes in / bytes out, and a Ristretto
 // encoding depends only on the group element, so the outputs stay bit-identical to the reference
-ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, u32* table, u32 n)
+ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, u32* table, u32* ring, u32 ring_slots, u32 n)
 {
     __shared__ int8_t sdig[66 * ZC_BLOCK];
     const int tid = threadIdx.x;
     const u32 wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u32 i = blockIdx.x * ZC_BLOCK + tid;             // a launch is at most FAST_CHUNK_LANES elements
+    const u32 i = blockIdx.x * ZC_BLOCK + tid;
     const bool valid = i < n;
     const u32 ii = valid ? i : 0;
     u64 w[4], l[5];
@@ -643,7 +718,10 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
     const bool dec = ris_decompress(P, w);
     if (!valid || !dec) top = -1;
     top = wave_max_small(top);
-    pt Q = scalar_mul_fast(P, table + 256 * (size_t)i, sdig + tid, ZC_BLOCK, top);
+    __shared__ u32 hold[ZC_BLOCK / 64];                    // the table slot is held for the multiplication only
+    const ring_table mine = ring_acquire(table, ring, hold + wave_in_block, ring_slots);
+    pt Q = scalar_mul_fast(P, mine, sdig + tid, ZC_BLOCK, top);
+    ring_release(ring, hold + wave_in_block);
     Q = pt_select(dec, Q, pt_identity());
     fe_to_words256(w, ris_compress(Q));
     if (!dec) w[0] = w[1] = w[2] = w[3] = 0;
@@ -652,7 +730,7 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
     // the lane number comes from v_mbcnt (a function of the lane position alone).  threadIdx.x itself
     // is a live-in VGPR, and anything derived from it stays live -- and gets spilled -- across the
     // three exponentiation-sized phases.
-    const u32 lane_late = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const u32 lane_late = lane_id_fresh();
     const u32 i_late = blockIdx.x * ZC_BLOCK + wave_in_block * 64u + lane_late;
     if (i_late < n) {
         store_words256(out + 32 * (size_t)i_late, w);

@@ -63,12 +63,10 @@ struct DevState {
     size_t bal_bytes = 0;
     void* msm = nullptr;                // bucket-method workspace (zc_msm)
     size_t msm_bytes = 0;
-    void* fast = nullptr;               // fast scalar-mul window tables: 1 KB per lane of a chunk
+    void* fast = nullptr;               // windowed-core tables: ring of wave slots, 256 MB (zc_kernels.cuh)
     size_t fast_bytes = 0;
-    void* fast2 = nullptr;              // the second chunk in flight (alternate chunks run on `aux`)
-    size_t fast2_bytes = 0;
-    hipStream_t aux = nullptr;          // forked from / joined to the launch stream with events
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void* ring = nullptr;               // tickets and slot flags of the table ring
+    size_t ring_bytes = 0;
     void* base_table = nullptr;         // comb table of the basepoint: 66 x 8 cached points
     size_t base_bytes = 0;
     void* part = nullptr;               // MSM exchange: gathered per-rank / per-device partials + the folded result
@@ -376,41 +374,32 @@ inline strict_kernel_t strict_kernel_for(size_t cnt)
 {
     return grid_for(cnt) <= SMALL_LAUNCH_BLOCKS ? zc::k_ed_scalar_mul_small : zc::k_ed_scalar_mul;
 }
-// The windowed-core kernels keep 1 KB of table scratch per lane.  A launch covers at most
-// FAST_CHUNK_LANES elements (four full rounds of three 256-thread workgroups per CU on 256 CUs, so no
-// chunk but the last ends in a partial round) and larger batches go chunk by chunk on the stream over
-// the same 768 MB of scratch.  ZC_FAST_CHUNK overrides (lanes).
-constexpr size_t FAST_CHUNK_LANES = (size_t)256 * 3 * 4 * 256;
-inline size_t fast_chunk()
+// The windowed-core kernels keep 1 KB of table scratch per lane in a ring of wave slots per XCD
+// (zc_kernels.cuh: ring_acquire / ring_release): 256 MB of tables plus 17 KB of tickets and flags, zeroed
+// on the stream before every launch.  One launch covers the batch (the kernels index with 32 bits:
+// beyond 2^31 elements the batch goes in pieces, one after the other on the stream).
+// launch(table, ring_state, slots_per_xcd, offset, count).  ZC_RING_SLOTS=k (1..512) shrinks the ring so that
+// waves really wait for one another (tests; the default leaves more slots than waves fit an XCD).
+constexpr size_t FAST_MAX_LAUNCH = (size_t)1 << 31;
+inline zc::u32 ring_slots()
 {
-    if (const char* e = getenv("ZC_FAST_CHUNK")) {
-        const long long v = atoll(e);
-        if (v >= 256 && v < (1ll << 31)) return (size_t)v / 256 * 256;
+    if (const char* e = getenv("ZC_RING_SLOTS")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= (long)zc::RING_SLOTS) return (zc::u32)v;
     }
-    return FAST_CHUNK_LANES;
+    return zc::RING_SLOTS;
 }
-// Chunks alternate between the launch stream and `aux`, each with its own table scratch, so the
-// next chunk's workgroups fill the slots the previous chunk's last round leaves free (one stream alone
-// drains the chip between chunks: +4 % at 2^22).  launch(stream, table, offset, count).
 template <class L>
-int fast_chunked(DevState& D, size_t cnt, L&& launch)
+int fast_ring(DevState& D, size_t cnt, L&& launch)
 {
-    const size_t chunk = fast_chunk();
-    int rc = ensure(&D.fast, &D.fast_bytes, std::min(chunk, (size_t)grid_for(cnt) * zc::ZC_BLOCK) * 1024);
+    int rc = ensure(&D.fast, &D.fast_bytes, zc::RING_TABLE_BYTES);
     if (rc) return rc;
-    if (cnt <= chunk) {
-        launch(D.s(), (zc::u32*)D.fast, (size_t)0, cnt);
-        return ZC_OK;
+    rc = ensure(&D.ring, &D.ring_bytes, zc::RING_STATE_WORDS * sizeof(zc::u32));
+    if (rc) return rc;
+    for (size_t off = 0; off < cnt; off += FAST_MAX_LAUNCH) {
+        HIP_TRY(hipMemsetAsync(D.ring, 0, zc::RING_STATE_WORDS * sizeof(zc::u32), D.s()));
+        launch((zc::u32*)D.fast, (zc::u32*)D.ring, ring_slots(), off, std::min(FAST_MAX_LAUNCH, cnt - off));
     }
-    rc = ensure(&D.fast2, &D.fast2_bytes, std::min(chunk, cnt - chunk + zc::ZC_BLOCK) * 1024);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(D.ev_fork, D.s()));
-    HIP_TRY(hipStreamWaitEvent(D.aux, D.ev_fork, 0));       // inputs are ready where the launch stream is now
-    size_t j = 0;
-    for (size_t off = 0; off < cnt; off += chunk, j++)
-        launch((j & 1) ? D.aux : D.s(), (zc::u32*)((j & 1) ? D.fast2 : D.fast), off, std::min(chunk, cnt - off));
-    HIP_TRY(hipEventRecord(D.ev_join, D.aux));
-    HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_join, 0));
     return ZC_OK;
 }
 int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
@@ -742,9 +731,6 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_in, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_out, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_order, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.aux, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming);
         if (e != hipSuccess) {
             delete ctx;
             return fail(ZC_ERR_HIP, "stream creation", e);
@@ -772,10 +758,7 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.bal) (void)hipFree(ds.bal);
         if (ds.msm) (void)hipFree(ds.msm);
         if (ds.fast) (void)hipFree(ds.fast);
-        if (ds.fast2) (void)hipFree(ds.fast2);
-        if (ds.aux) { (void)hipStreamSynchronize(ds.aux); (void)hipStreamDestroy(ds.aux); }
-        if (ds.ev_fork) (void)hipEventDestroy(ds.ev_fork);
-        if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
+        if (ds.ring) (void)hipFree(ds.ring);
         if (ds.base_table) (void)hipFree(ds.base_table);
         for (hipEvent_t e : ds.ev) (void)hipEventDestroy(e);
         if (ds.copy_in) (void)hipStreamDestroy(ds.copy_in);
@@ -944,9 +927,9 @@ int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t
         Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
         int inner = ZC_OK;
         int rc = run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-            inner = fast_chunked(D, cnt, [&](hipStream_t st, zc::u32* table, size_t off, size_t c) {
-                hipLaunchKernelGGL(zc::k_ed_scalar_mul_fast, dim3(grid_for(c)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)d[0] + 20 * off,
-                                   (const u64*)d[1] + 5 * off, (zc::u32)5, (u64*)d[2] + 20 * off, table, (zc::u32)c);
+            inner = fast_ring(D, cnt, [&](zc::u32* table, zc::u32* ring, zc::u32 slots, size_t off, size_t c) {
+                hipLaunchKernelGGL(zc::k_ed_scalar_mul_fast, dim3(grid_for(c)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0] + 20 * off,
+                                   (const u64*)d[1] + 5 * off, (zc::u32)5, (u64*)d[2] + 20 * off, table, ring, slots, (zc::u32)c);
             });
         }, true);
         return rc ? rc : inner;
@@ -1045,9 +1028,9 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
             hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
             return;
         }
-        inner = fast_chunked(D, cnt, [&](hipStream_t st, zc::u32* table, size_t off, size_t c) {
-            hipLaunchKernelGGL(zc::k_ris_roundtrip_mul_fast, dim3(grid_for(c)), dim3(zc::ZC_BLOCK), 0, st, (const uint8_t*)d[0] + 32 * off,
-                               (const u64*)d[1] + 5 * off, (uint8_t*)d[2] + 32 * off, d[3] ? (uint8_t*)d[3] + off : (uint8_t*)nullptr, table, (zc::u32)c);
+        inner = fast_ring(D, cnt, [&](zc::u32* table, zc::u32* ring, zc::u32 slots, size_t off, size_t c) {
+            hipLaunchKernelGGL(zc::k_ris_roundtrip_mul_fast, dim3(grid_for(c)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0] + 32 * off,
+                               (const u64*)d[1] + 5 * off, (uint8_t*)d[2] + 32 * off, d[3] ? (uint8_t*)d[3] + off : (uint8_t*)nullptr, table, ring, slots, (zc::u32)c);
         });
     }, true);
     return rc ? rc : inner;

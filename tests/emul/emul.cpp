@@ -216,7 +216,7 @@ extern "C" void emul_ed_scalar_mul_fast(const u64* p, const u64* k, u64* out, si
         alignas(128) u32 table[256];
         int8_t dig[66];
         const int top = scalar_digits16(dig, 1, l);
-        pt_store(out + 20 * i, scalar_mul_fast(pt_load(p + 20 * i), table, dig, 1, top));
+        pt_store(out + 20 * i, scalar_mul_fast(pt_load(p + 20 * i), table_ptr{table}, dig, 1, top));
     }
 }
 // the termination rule of double_and_add on raw 260-bit patterns (scalar_effective) and the bit

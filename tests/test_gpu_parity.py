@@ -554,6 +554,39 @@ def test_ristretto_roundtrip_full_size_2_22(eng, oracle):
     assert eq(ok1[slab], wok) and eq(r1[slab], wout) and (wok == 0).sum() > 1000
 
 
+def test_windowed_core_table_ring_under_contention(eng, oracle, monkeypatch):
+    """The windowed core keeps its per-lane tables in a ring of wave slots per XCD (ring_acquire /
+    ring_release, zc_kernels.cuh).  With the default 512 slots per XCD a wave practically never waits
+    for a slot; ZC_RING_SLOTS shrinks the ring far below the number of resident waves, so that every
+    slot is handed from wave to wave many times inside one launch.  Bytes, ok masks and points must
+    not depend on the ring size, and must equal the oracle's."""
+    import dusk_zerocaf_amd as z
+    n = (1 << 16) + 333
+    P = V.base_multiples(oracle, 1 << 10, V.SEED + 140)
+    P = np.tile(P, (n // 1024 + 1, 1))[:n]
+    enc = np.tile(oracle.ris_compress(P[:1024]), (n // 1024 + 1, 1))[:n]
+    rng = np.random.default_rng(V.SEED + 141)
+    bad = rng.choice(n, size=n // 100, replace=False)
+    enc[bad, :8] ^= rng.integers(1, 256, size=(len(bad), 8), dtype=np.uint8)
+    K = V.rand_scalars_np(n, V.SEED + 142, bits=252)
+    _edge_scalars(K)
+    ref_out, ref_ok = eng.ris_roundtrip_mul(enc, K)
+    ref_pts = eng.ed_scalar_mul(P, K, flags=z.FAST)
+    idx = np.arange(0, n, 37)
+    wout, wok = oracle.mt(oracle.ris_roundtrip_mul, enc[idx], K[idx])
+    assert eq(ref_out[idx], wout) and eq(ref_ok[idx], wok)
+    for slots in ("96", "7", "1"):                                 # 384 waves are resident per XCD
+        monkeypatch.setenv("ZC_RING_SLOTS", slots)
+        m = n if slots != "1" else 1 << 13                          # one slot per XCD serialises the XCD's waves
+        out, ok = eng.ris_roundtrip_mul(enc[:m], K[:m])
+        assert eq(out, ref_out[:m]) and eq(ok, ref_ok[:m]), "ring of %s slots per XCD" % slots
+        pts = eng.ed_scalar_mul(P[:m], K[:m], flags=z.FAST)
+        assert eq(pts, ref_pts[:m]), "ring of %s slots per XCD (points)" % slots
+    monkeypatch.delenv("ZC_RING_SLOTS")
+    out, ok = eng.ris_roundtrip_mul(enc, K)                        # and the state is reset per launch
+    assert eq(out, ref_out) and eq(ok, ref_ok)
+
+
 def test_next_rows_elligator_validity_projective(eng, oracle, kats):
     """Elligator + from_uniform_bytes, is_valid (Edwards and Ristretto),
     ProjectivePoint add/double -- limb-exact vs the oracle, reference KATs included."""
