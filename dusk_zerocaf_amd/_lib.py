@@ -39,6 +39,12 @@ SIGNATURES = {
     "zc_sc_neg": [_u64p, _u64p, _n],
     "zc_sc_mul": [_u64p, _u64p, _u64p, _n],
     "zc_sc_square": [_u64p, _u64p, _n],
+    "zc_fe_inv_sqrt": [_u64p, _u64p, _u8p, _n],
+    "zc_sc_half": [_u64p, _u64p, _n],
+    "zc_sc_pow": [_u64p, _u64p, _u64p, _n],
+    "zc_sc_shr": [_u64p, C.c_uint, _u64p, _n],
+    "zc_sc_into_bits": [_u64p, _u8p, _n],
+    "zc_sc_compute_naf": [_u64p, C.c_uint, _u8p, _n],
     "zc_sc_from_bytes": [_u8p, _u64p, _u8p, _n],
     "zc_sc_to_bytes": [_u64p, _u8p, _n],
     "zc_ed_add": [_u64p, _u64p, _u64p, _n],

@@ -358,6 +358,117 @@ ZC_KERNEL void k_to_bytes(const u64* in, uint8_t* out, size_t n)
     store_words256(out + 32 * i, w);
 }
 
+// ---- S-x / F8 rows of SURVEY 8(a) that sit beside the default path: Scalar Half / Pow / Shr, the bit and
+// NAF recoders behind ltr_bin_mul / binary_naf_mul / window_naf_mul, FieldElement inv_sqrt
+ZC_KERNEL void k_fe_inv_sqrt(const u64* a, u64* out, uint8_t* was_square, size_t n)  // field.rs:443-460 = sqrt_ratio_i(1, a)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    fe r;
+    const bool sq = fp_sqrt_ratio_i(r, fe_one_m<FP>(), fe_load_mont<FP>(a + 5 * i));
+    fe_store_canon<FP>(out + 5 * i, r);
+    if (was_square) was_square[i] = sq ? 1 : 0;
+}
+ZC_KERNEL void k_sc_half(const u64* a, u64* out, size_t n)                           // scalar.rs:285-291 (a * INVERSE_MOD_TWO)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5], h[5];
+    load5(l, a + 5 * i);
+    fe_to_limbs52(h, fe_n_minus_canon<ModL>(fe_const<ModL>(ModL::HALF)));            // (L+1)/2 = L - (L-1)/2
+    const fe p2 = mont_mul<ModL>(mont_to<ModL>(fe_from_limbs52(l)), fe_from_limbs52(h));
+    fe_to_limbs52(h, fe_cond_sub_n<ModL>(fe_cond_sub_n<ModL>(p2)));
+    store5(out + 5 * i, h);
+}
+// scalar.rs:300-322: square-and-multiply driven by halving the exponent; for a canonical exponent that is
+// a^e mod L (e = 0 gives 1), computed here MSB-first on the fixed 261-bit schedule
+ZC_KERNEL void k_sc_pow(const u64* a, const u64* e, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5];
+    load5(l, e + 5 * i);
+    const fe ee = fe_from_limbs52(l);
+    const fe am = fe_load_mont<ModL>(a + 5 * i);
+    fe acc = fe_one_m<ModL>();
+    for (int b = 260; b >= 0; b--) {
+        acc = mont_sqr<ModL>(acc);
+        const bool bit = ((ee.v[b / 29] >> (b % 29)) & 1) != 0;
+        acc = fe_select(bit, mont_mul<ModL>(acc, am), acc);
+    }
+    fe_store_canon<ModL>(out + 5 * i, acc);
+}
+// half_without_mod (scalar.rs:562-574): the five limbs as one 260-bit integer, shifted right by one
+ZC_DI void half_without_mod52(u64 (&k)[5])
+{
+#pragma unroll
+    for (int j = 0; j < 5; j++) k[j] = (k[j] >> 1) | (j < 4 ? (k[j + 1] & 1) << 51 : 0);
+}
+ZC_KERNEL void k_sc_shr(const u64* a, u32 shift, u64* out, size_t n)                 // Shr<u8>, scalar.rs:165-182
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 k[5];
+    load5(k, a + 5 * i);
+    for (u32 s = 0; s < shift; s++) half_without_mod52(k);
+    store5(out + 5 * i, k);
+}
+ZC_KERNEL void k_sc_into_bits(const u64* a, uint8_t* out, size_t n)                  // scalar.rs:352-366: the bits of to_bytes()
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5], w[4];
+    load5(l, a + 5 * i);
+    limbs52_to_words(w, l);
+    u32* o = reinterpret_cast<u32*>(out + 256 * i);
+    for (int q = 0; q < 64; q++) {
+        const u32 nib = (u32)(w[q >> 4] >> ((q & 15) * 4)) & 15u;
+        o[q] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+    }
+}
+// compute_NAF (scalar.rs:370-389; width == 0) and compute_window_NAF (scalar.rs:396-415; width 2..7), the
+// reference's loop literally: while k >= 1 and i < 256 { if k is odd { k_i = 2 - (k mod 4) | mods(k, 2^w);
+// k = k - Scalar::from(k_i) } ; k = half_without_mod(k) }, where Scalar::from of a negative digit is L - |k_i|
+// (scalar.rs:68-84) and Sub adds L back only after a borrow (:210-237) -- so a scalar above L - |k_i| takes the
+// reference's wrap-around, not the integer NAF.  256 digits per scalar, zeros behind the last one.
+ZC_KERNEL void k_sc_compute_naf(const u64* a, u32 width, int8_t* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 k[5], m[5];
+    load5(k, a + 5 * i);
+    limbs52_of_modulus<ModL>(m);
+    u32* o = reinterpret_cast<u32*>(out + 256 * i);
+    u32 packed = 0;
+    for (int d = 0; d < 256; d++) {
+        int ki = 0;
+        if (((k[0] | k[1] | k[2] | k[3] | k[4]) != 0) && (k[0] & 1)) {
+            if (width == 0) ki = 2 - (int)(k[0] & 3);
+            else {
+                const int modulus = (int)(k[0] & ((1u << width) - 1u));                  // mods_2_pow_k, scalar.rs:433-442
+                ki = modulus >= (1 << (width - 1)) ? modulus - (1 << width) : modulus;
+            }
+            u64 t[5] = {(u64)(ki < 0 ? -ki : ki), 0, 0, 0, 0}, r[5];
+            if (ki < 0) {
+                const u64 z[5] = {0, 0, 0, 0, 0};
+                sub52(r, z, t, m);                                                       // Neg: 0 - |k_i| mod L
+#pragma unroll
+                for (int j = 0; j < 5; j++) t[j] = r[j];
+            }
+            sub52(r, k, t, m);
+#pragma unroll
+            for (int j = 0; j < 5; j++) k[j] = r[j];
+        }
+        half_without_mod52(k);
+        packed |= ((u32)ki & 0xFFu) << (8 * (d & 3));
+        if ((d & 3) == 3) {
+            o[d >> 2] = packed;
+            packed = 0;
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------ point ops
 ZC_KERNEL void k_ed_add(const u64* p, const u64* q, u64* out, size_t n)
 {

@@ -896,6 +896,14 @@ int zc_fe_sqrt_ratio_i(zc_ctx* ctx, const uint64_t* u, const uint64_t* v, uint64
         hipLaunchKernelGGL(zc::k_fe_sqrt_ratio_i, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
     });
 }
+int zc_fe_inv_sqrt(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* was_square, size_t n)
+{
+    REQUIRE(a); REQUIRE(out);
+    Arg args[3] = {in_arg(a, 40), out_arg(out, 40), out_arg(was_square, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_fe_inv_sqrt, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
 
 // ---- Scalar
 int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, zc::k_sc_add_stream, a, b, o, n, 40); }
@@ -903,6 +911,35 @@ int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size
 int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, nullptr, a, b, o, n, 40); }
 int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40); }
 int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40); }
+// S-x rows: the Scalar operations beside the default scalar-mul path
+int zc_sc_half(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_half, a, o, n, 40); }
+int zc_sc_pow(zc_ctx* c, const uint64_t* a, const uint64_t* e, uint64_t* o, size_t n) { return binop(c, zc::k_sc_pow, nullptr, a, e, o, n, 40); }
+int zc_sc_shr(zc_ctx* ctx, const uint64_t* a, unsigned shift, uint64_t* out, size_t n)
+{
+    REQUIRE(a); REQUIRE(out);
+    if (shift > 255) return fail(ZC_ERR_BAD_ARG, "zc_sc_shr: the reference shifts by a u8");
+    Arg args[2] = {in_arg(a, 40), out_arg(out, 40)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_sc_shr, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (zc::u32)shift, (u64*)d[1], cnt);
+    });
+}
+int zc_sc_into_bits(zc_ctx* ctx, const uint64_t* a, uint8_t* bits256, size_t n)
+{
+    REQUIRE(a); REQUIRE(bits256);
+    Arg args[2] = {in_arg(a, 40), out_arg(bits256, 256)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_sc_into_bits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_sc_compute_naf(zc_ctx* ctx, const uint64_t* a, unsigned width, int8_t* naf256, size_t n)
+{
+    REQUIRE(a); REQUIRE(naf256);
+    if (width == 1 || width > 7) return fail(ZC_ERR_BAD_ARG, "zc_sc_compute_naf: width 0 (compute_NAF) or 2..7 (compute_window_NAF: digits are i8)");
+    Arg args[2] = {in_arg(a, 40), out_arg(naf256, 256)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_sc_compute_naf, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (zc::u32)width, (int8_t*)d[1], cnt);
+    });
+}
 int zc_sc_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(in32); REQUIRE(out);

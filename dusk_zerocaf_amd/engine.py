@@ -182,6 +182,14 @@ class Engine:
         self._call("zc_fe_sqrt_ratio_i", pu, pv, po, ps, n)
         return out, sq
 
+    def fe_inv_sqrt(self, a):
+        """InvSqrt (field.rs:443-460): (1/sqrt(a) or sqrt(i/a), was_square)."""
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 5, np.uint64)
+        sq, ps = self._alloc(a, n, 0, np.uint8)
+        self._call("zc_fe_inv_sqrt", pa, po, ps, n)
+        return out, sq
+
     def _alloc_u64(self, like, n, width):
         if _is_torch(like):
             import torch
@@ -196,6 +204,33 @@ class Engine:
     def sc_mul(self, a, b): return self._bin("zc_sc_mul", a, b, 5)
     def sc_neg(self, a): return self._un("zc_sc_neg", a, 5)
     def sc_square(self, a): return self._un("zc_sc_square", a, 5)
+
+    # the Scalar operations beside the default scalar-mul path (scalar.rs:165-182, 285-322, 352-415)
+    def sc_half(self, a): return self._un("zc_sc_half", a, 5)
+    def sc_pow(self, a, e): return self._bin("zc_sc_pow", a, e, 5)
+
+    def sc_shr(self, a, shift):
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 5, np.uint64)
+        self._call("zc_sc_shr", pa, C.c_uint(int(shift)), po, n)
+        return out
+
+    def sc_into_bits(self, a):
+        """into_bits: (n, 256) uint8, the bits of to_bytes(), least significant first."""
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 256, np.uint8)
+        self._call("zc_sc_into_bits", pa, po, n)
+        return out
+
+    def sc_compute_naf(self, a, width=0):
+        """compute_NAF (width 0) / compute_window_NAF(width 2..7): (n, 256) int8 digits."""
+        a, pa, n = self._prep(a, 5, np.uint64)
+        out, po = self._alloc(a, n, 256, np.uint8)
+        self._call("zc_sc_compute_naf", pa, C.c_uint(int(width)), po, n)
+        if _is_torch(out):
+            import torch
+            return out.view(torch.int8)
+        return out.view(np.int8)
 
     def sc_from_bytes(self, b):
         b, pb, n = self._prep(b, 32, np.uint8)

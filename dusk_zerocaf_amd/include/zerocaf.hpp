@@ -133,7 +133,13 @@ struct FieldElement {
         Backend::check(zc_fe_sqrt_ratio_i(Backend::ctx(), l.data(), v.l.data(), r.l.data(), &sq, 1), "zc_fe_sqrt_ratio_i");
         return {sq != 0, r};
     }
-    std::pair<bool, FieldElement> inv_sqrt() const { return one().sqrt_ratio_i(*this); }
+    std::pair<bool, FieldElement> inv_sqrt() const                                      // InvSqrt, field.rs:443-460
+    {
+        FieldElement r;
+        uint8_t sq = 0;
+        Backend::check(zc_fe_inv_sqrt(Backend::ctx(), l.data(), r.l.data(), &sq, 1), "zc_fe_inv_sqrt");
+        return {sq != 0, r};
+    }
     static FieldElement from_bytes(const std::array<uint8_t, 32>& b)
     {
         FieldElement r;
@@ -180,6 +186,27 @@ struct Scalar {
     Scalar operator*(const Scalar& b) const { Scalar r; Backend::check(zc_sc_mul(Backend::ctx(), l.data(), b.l.data(), r.l.data(), 1), "zc_sc_mul"); return r; }
     Scalar operator-() const { Scalar r; Backend::check(zc_sc_neg(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_neg"); return r; }
     Scalar square() const { Scalar r; Backend::check(zc_sc_square(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_square"); return r; }
+    Scalar half() const { Scalar r; Backend::check(zc_sc_half(Backend::ctx(), l.data(), r.l.data(), 1), "zc_sc_half"); return r; }   // Half, scalar.rs:285-291
+    Scalar pow(const Scalar& e) const { Scalar r; Backend::check(zc_sc_pow(Backend::ctx(), l.data(), e.l.data(), r.l.data(), 1), "zc_sc_pow"); return r; }   // Pow, :300-322
+    Scalar operator>>(uint8_t k) const { Scalar r; Backend::check(zc_sc_shr(Backend::ctx(), l.data(), k, r.l.data(), 1), "zc_sc_shr"); return r; }            // Shr<u8>, :165-182
+    std::array<uint8_t, 256> into_bits() const                               // scalar.rs:352-366
+    {
+        std::array<uint8_t, 256> b{};
+        Backend::check(zc_sc_into_bits(Backend::ctx(), l.data(), b.data(), 1), "zc_sc_into_bits");
+        return b;
+    }
+    std::array<int8_t, 256> compute_NAF() const                              // scalar.rs:370-389
+    {
+        std::array<int8_t, 256> d{};
+        Backend::check(zc_sc_compute_naf(Backend::ctx(), l.data(), 0, d.data(), 1), "zc_sc_compute_naf");
+        return d;
+    }
+    std::array<int8_t, 256> compute_window_NAF(uint8_t width) const          // scalar.rs:396-415
+    {
+        std::array<int8_t, 256> d{};
+        Backend::check(zc_sc_compute_naf(Backend::ctx(), l.data(), width, d.data(), 1), "zc_sc_compute_naf");
+        return d;
+    }
     bool is_even() const { return (l[0] & 1) == 0; }                         // scalar.rs:346-348
     Scalar half_without_mod() const                                         // scalar.rs:562-574
     {

@@ -117,6 +117,8 @@ int zc_fe_to_bytes(zc_ctx *ctx, const uint64_t *in, uint8_t *out32, size_t n);
 /* SqrtRatioI: field.rs:462-503 (InvSqrt :443-460 is u = 1) */
 int zc_fe_sqrt_ratio_i(zc_ctx *ctx, const uint64_t *u, const uint64_t *v, uint64_t *out,
                        uint8_t *was_square, size_t n);
+/* InvSqrt: field.rs:443-460 -- (was_square, 1/sqrt(a)) or (0, sqrt(i/a)); (0, 0) for a = 0 */
+int zc_fe_inv_sqrt(zc_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *was_square, size_t n);
 
 /* ---- Scalar (mod L = 2^249 + 14490550575682688738086195780655237219) --------- */
 /* Add: src/backend/u64/scalar.rs:184-200  Sub: :210-237  Neg: :139-155          */
@@ -129,6 +131,21 @@ int zc_sc_square(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 /* from_bytes: scalar.rs:445-467 (asserts <= L-1 -> ok[i] = 0)   to_bytes: :477-516 */
 int zc_sc_from_bytes(zc_ctx *ctx, const uint8_t *in32, uint64_t *out, uint8_t *ok, size_t n);
 int zc_sc_to_bytes(zc_ctx *ctx, const uint64_t *in, uint8_t *out32, size_t n);
+/* The Scalar operations beside the default scalar-mul path (SURVEY 8a row S-x).
+ * Half: scalar.rs:285-291   Pow: :300-322 (e: canonical limbs; e = 0 gives 1)
+ * Shr<u8>: :165-182 (the five limbs as one 260-bit integer shifted right, no reduction) */
+int zc_sc_half(zc_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int zc_sc_pow(zc_ctx *ctx, const uint64_t *a, const uint64_t *e, uint64_t *out, size_t n);
+int zc_sc_shr(zc_ctx *ctx, const uint64_t *a, unsigned shift, uint64_t *out, size_t n);
+/* into_bits: scalar.rs:352-366 -- 256 bytes of 0/1 per scalar, the bits of to_bytes(), least significant first
+ * (what ltr_bin_mul walks, edwards.rs:122-134) */
+int zc_sc_into_bits(zc_ctx *ctx, const uint64_t *a, uint8_t *bits256, size_t n);
+/* width = 0: compute_NAF, scalar.rs:370-389 (digits -1/0/1; what binary_naf_mul walks, edwards.rs:136-153)
+ * width = 2..7: compute_window_NAF(width), scalar.rs:396-415 with mods_2_pow_k :433-442 (odd digits in
+ * (-2^(w-1), 2^(w-1)); what window_naf_mul walks, edwards.rs:155-171).  256 int8 digits per scalar, least
+ * significant first, zeros behind the last.  The reference's modular `k - Scalar::from(k_i)` is reproduced,
+ * wrap-around near L included. */
+int zc_sc_compute_naf(zc_ctx *ctx, const uint64_t *a, unsigned width, int8_t *naf256, size_t n);
 
 /* ---- EdwardsPoint ------------------------------------------------------------ */
 /* Add: src/edwards.rs:465-501   Sub: :503-545   Double: :579-592 (= add)   Neg: :440-463 */

@@ -354,6 +354,14 @@ impl HipBackend {
         Ok(sq.into_iter().map(|s| s == 1).zip(unflat_fe(&out)).collect())
     }
 
+    /// `a.inv_sqrt()` (`:443-460`): `(was_square, root)`.
+    pub fn fe_inv_sqrt(&self, a: &[FieldElement]) -> Result<Vec<(bool, FieldElement)>> {
+        let (fa, n) = (flat_fe(a), a.len());
+        let (mut out, mut sq) = (vec![0u64; n * 5], vec![0u8; n]);
+        check(unsafe { ffi::zc_fe_inv_sqrt(self.ctx, fa.as_ptr(), out.as_mut_ptr(), sq.as_mut_ptr(), n) })?;
+        Ok(sq.into_iter().map(|s| s == 1).zip(unflat_fe(&out)).collect())
+    }
+
     /// `FieldElement::from_bytes` (`:563-587`).
     pub fn fe_from_bytes(&self, bytes: &[[u8; 32]]) -> Result<Vec<FieldElement>> {
         let flat: Vec<u8> = bytes.iter().flat_map(|b| b.iter().copied()).collect();
@@ -398,6 +406,41 @@ impl HipBackend {
     /// `a.square()` (`:272-283`).
     pub fn sc_square(&self, a: &[Scalar]) -> Result<Vec<Scalar>> {
         Ok(unflat_sc(&self.un(ffi::zc_sc_square, &flat_sc(a), a.len(), 5)?))
+    }
+
+    /// `a.half()` (`:285-291`).
+    pub fn sc_half(&self, a: &[Scalar]) -> Result<Vec<Scalar>> {
+        Ok(unflat_sc(&self.un(ffi::zc_sc_half, &flat_sc(a), a.len(), 5)?))
+    }
+
+    /// `a.pow(&e)` (`:300-322`).
+    pub fn sc_pow(&self, a: &[Scalar], e: &[Scalar]) -> Result<Vec<Scalar>> {
+        assert_eq!(a.len(), e.len());
+        Ok(unflat_sc(&self.bin(ffi::zc_sc_pow, &flat_sc(a), &flat_sc(e), a.len(), 5)?))
+    }
+
+    /// `a >> shift` (`Shr<u8>`, `:165-182`).
+    pub fn sc_shr(&self, a: &[Scalar], shift: u8) -> Result<Vec<Scalar>> {
+        let (fa, n) = (flat_sc(a), a.len());
+        let mut out = vec![0u64; n * 5];
+        check(unsafe { ffi::zc_sc_shr(self.ctx, fa.as_ptr(), shift as c_uint, out.as_mut_ptr(), n) })?;
+        Ok(unflat_sc(&out))
+    }
+
+    /// `a.into_bits()` (`:352-366`).
+    pub fn sc_into_bits(&self, a: &[Scalar]) -> Result<Vec<[u8; 256]>> {
+        let (fa, n) = (flat_sc(a), a.len());
+        let mut out = vec![0u8; n * 256];
+        check(unsafe { ffi::zc_sc_into_bits(self.ctx, fa.as_ptr(), out.as_mut_ptr(), n) })?;
+        Ok(out.chunks_exact(256).map(|c| { let mut b = [0u8; 256]; b.copy_from_slice(c); b }).collect())
+    }
+
+    /// `a.compute_NAF()` (`width == 0`, `:370-389`) / `a.compute_window_NAF(width)` (`:396-415`).
+    pub fn sc_compute_naf(&self, a: &[Scalar], width: u8) -> Result<Vec<[i8; 256]>> {
+        let (fa, n) = (flat_sc(a), a.len());
+        let mut out = vec![0i8; n * 256];
+        check(unsafe { ffi::zc_sc_compute_naf(self.ctx, fa.as_ptr(), width as c_uint, out.as_mut_ptr(), n) })?;
+        Ok(out.chunks_exact(256).map(|c| { let mut d = [0i8; 256]; d.copy_from_slice(c); d }).collect())
     }
 
     /// `Scalar::from_bytes` (`:445-467`); `None` where the reference asserts (value > L - 1).

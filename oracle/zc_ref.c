@@ -1064,6 +1064,22 @@ BINOP_BATCH(zr_sc_sub_batch, zr_sc_sub)
 BINOP_BATCH(zr_sc_mul_batch, zr_sc_mul)
 UNOP_BATCH(zr_sc_neg_batch, zr_sc_neg)
 UNOP_BATCH(zr_sc_square_batch, zr_sc_square)
+UNOP_BATCH(zr_sc_half_batch, zr_sc_half)
+BINOP_BATCH(zr_sc_pow_batch, zr_sc_pow)
+void zr_sc_shr_batch(const uint64_t *a, unsigned shift, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) { zr_fe r; zr_sc_shr(&r, FE(a, i), shift); *FEO(out, i) = r; } }
+void zr_sc_into_bits_batch(const uint64_t *a, uint8_t *bits, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_sc_into_bits(bits + 256 * i, FE(a, i)); }
+/* width 0: compute_NAF (S:370-389); otherwise compute_window_NAF(width) (S:396-415) */
+void zr_sc_compute_naf_batch(const uint64_t *a, unsigned width, int8_t *naf, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (width == 0) zr_sc_compute_naf(naf + 256 * i, FE(a, i));
+        else zr_sc_compute_window_naf(naf + 256 * i, FE(a, i), width);
+    }
+}
+void zr_fe_inv_sqrt_batch(const uint64_t *a, uint64_t *out, uint8_t *was_square, size_t n)
+{ for (size_t i = 0; i < n; i++) { zr_fe r; int c = zr_fe_inv_sqrt(&r, FE(a, i)); *FEO(out, i) = r; if (was_square) was_square[i] = (uint8_t)c; } }
 
 void zr_fe_invert_batch(const uint64_t *a, uint64_t *out, uint8_t *ok, size_t n)
 {

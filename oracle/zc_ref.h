@@ -129,6 +129,12 @@ void zr_sc_sub_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t
 void zr_sc_mul_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 void zr_sc_neg_batch(const uint64_t *a, uint64_t *out, size_t n);
 void zr_sc_square_batch(const uint64_t *a, uint64_t *out, size_t n);
+void zr_sc_half_batch(const uint64_t *a, uint64_t *out, size_t n);
+void zr_sc_pow_batch(const uint64_t *a, const uint64_t *e, uint64_t *out, size_t n);
+void zr_sc_shr_batch(const uint64_t *a, unsigned shift, uint64_t *out, size_t n);
+void zr_sc_into_bits_batch(const uint64_t *a, uint8_t *bits, size_t n);
+void zr_sc_compute_naf_batch(const uint64_t *a, unsigned width, int8_t *naf, size_t n);
+void zr_fe_inv_sqrt_batch(const uint64_t *a, uint64_t *out, uint8_t *was_square, size_t n);
 void zr_sc_from_bytes_batch(const uint8_t *in, uint64_t *out, uint8_t *ok, size_t n);
 void zr_sc_to_bytes_batch(const uint64_t *in, uint8_t *out, size_t n);
 void zr_ed_add_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);

@@ -148,6 +148,39 @@ def fe_sqrt_ratio_i(u, v):
     return out, sq
 
 
+sc_half = _unop("zr_sc_half_batch", 5)
+sc_pow = _binop("zr_sc_pow_batch", 5)
+
+
+def sc_shr(a, shift):
+    a = _u64(a, 5)
+    out = np.empty_like(a)
+    lib().zr_sc_shr_batch(_p(a), C.c_uint(int(shift)), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
+def sc_into_bits(a):
+    a = _u64(a, 5)
+    out = np.empty((a.shape[0], 256), dtype=np.uint8)
+    lib().zr_sc_into_bits_batch(_p(a), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
+def sc_compute_naf(a, width=0):
+    a = _u64(a, 5)
+    out = np.empty((a.shape[0], 256), dtype=np.int8)
+    lib().zr_sc_compute_naf_batch(_p(a), C.c_uint(int(width)), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
+def fe_inv_sqrt(a):
+    a = _u64(a, 5)
+    out = np.empty_like(a)
+    sq = np.empty(a.shape[0], dtype=np.uint8)
+    lib().zr_fe_inv_sqrt_batch(_p(a), _p(out), _p(sq), C.c_size_t(a.shape[0]))
+    return out, sq
+
+
 def sc_from_bytes(b):
     b = _u8(b)
     out = np.empty((b.shape[0], 5), dtype=np.uint64)

@@ -59,6 +59,53 @@ def test_kat_scalar(eng, kats):
     assert ok.tolist() == [1, 0] and eq(eng.sc_to_bytes(out[:1]), okb[:1])
 
 
+def test_scalar_rows_beside_the_path_half_pow_shr_bits_naf(eng, oracle, kats):
+    """SURVEY 8(a) row S-x (Scalar Half / Pow / Shr, into_bits, compute_NAF, compute_window_NAF) and
+    FieldElement inv_sqrt: the reference's KATs, then bulk vs the oracle -- canonical scalars for the
+    modular ops, raw 5 x 52-bit patterns (values above L included) for the shifts and recoders, whose
+    reference behaviour (Sub adds L back only after a borrow) is reproduced literally."""
+    s = lambda n: np.array([kats["scalar"][n]["limbs"]], dtype=np.uint64)
+    row = lambda *l: np.array([list(l)], dtype=np.uint64)
+    assert eq(eng.sc_half(s("Y")), s("Y_HALF"))                                         # scalar.rs tests: half
+    assert eq(eng.sc_half(eng.sc_half(s("A"))), row(0, 0, 2251799813685248, 0, 0))
+    assert eq(eng.sc_pow(s("A"), s("B")), s("A_POW_B"))                                 # pow
+    assert eq(eng.sc_shr(s("A"), 1), row(0, 0, 0, 1, 0)) and not eng.sc_shr(row(1, 0, 0, 0, 0), 1).any()
+    assert eq(eng.sc_shr(row(0, 0, 0, 0, 2199023255552), 248), row(2, 0, 0, 0, 0))
+    bits = eng.sc_into_bits(np.concatenate([row(9, 0, 0, 0, 0), row(0, 0, 0, 0, 2199023255552)]))
+    assert bits[0].nonzero()[0].tolist() == [0, 3] and bits[1].nonzero()[0].tolist() == [249]
+    assert eng.sc_compute_naf(row(7, 0, 0, 0, 0))[0, :4].tolist() == [-1, 0, 0, 1]     # scalar.rs:1024-1026
+    w = row(1122334455, 0, 0, 0, 0)                                                     # scalar.rs:1031-1050
+    assert eng.sc_compute_naf(w, 4)[0, :31].tolist() == [7, 0, 0, 0, -1, 0, 0, 0, 7, 0, 0, 0, 7, 0, 0, 0, 5, 0, 0, 0, 0, 7, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    assert eng.sc_compute_naf(w, 5)[0, :32].tolist() == [-9, 0, 0, 0, 0, 0, 0, 0, -9, 0, 0, 0, 0, 0, 0, 11, 0, 0, 0, 0, 0, -9, 0, 0, 0, 0, -15, 0, 0, 0, 0, 1]
+    n = 3000 + 7
+    a = V.rand_fe_np(n, V.SEED + 150, pm.L)
+    e = V.rand_fe_np(n, V.SEED + 151, pm.L)
+    e[0] = 0
+    e[1] = [1, 0, 0, 0, 0]
+    a[2] = 0
+    assert eq(eng.sc_half(a), oracle.sc_half(a))
+    assert eq(eng.sc_pow(a[:600], e[:600]), oracle.sc_pow(a[:600], e[:600]))
+    raw = V.rand_scalars_np(n, V.SEED + 152, bits=260)
+    raw[0] = 0
+    raw[1] = (1 << 52) - 1
+    raw[2] = pm.limbs(pm.L)
+    raw[3] = pm.limbs(pm.L - 1)
+    raw[4] = pm.limbs(pm.L + 1)
+    raw[5] = pm.limbs(pm.L - 2)
+    for sh in (0, 1, 51, 52, 53, 200, 255):
+        assert eq(eng.sc_shr(raw, sh), oracle.sc_shr(raw, sh)), sh
+    assert eq(eng.sc_into_bits(raw), oracle.sc_into_bits(raw))
+    for width in (0, 2, 3, 4, 5, 6, 7):
+        both = np.concatenate([a, raw])
+        assert eq(eng.sc_compute_naf(both, width), oracle.sc_compute_naf(both, width)), width
+    x = V.rand_fe_np(n, V.SEED + 153, pm.P)
+    x[0] = 0
+    x[1] = [27, 0, 0, 0, 0]
+    got, sq = eng.fe_inv_sqrt(x)
+    want, wsq = oracle.fe_inv_sqrt(x)
+    assert eq(got, want) and eq(sq, wsq) and 0 < sq.sum() < n
+
+
 def test_kat_edwards_and_ristretto(eng, kats):
     def ept(name):
         c = kats["edwards_points"][name]["coords"]
