@@ -69,6 +69,12 @@ SIGNATURES = {
     "zc_proj_add": [_u64p, _u64p, _u64p, _n],
     "zc_proj_double": [_u64p, _u64p, _n],
     "zc_proj_to_extended": [_u64p, _u64p, _n],
+    "zc_proj_neg": [_u64p, _u64p, _n],
+    "zc_proj_sub": [_u64p, _u64p, _u64p, _n],
+    "zc_proj_eq": [_u64p, _u64p, _u8p, _n],
+    "zc_proj_is_valid": [_u64p, _u8p, _n],
+    "zc_proj_scalar_mul": [_u64p, _u64p, _u64p, _n],
+    "zc_ed_coset4": [_u64p, _u64p, _n],
     "zc_ed_mul_base": [_u64p, _u64p, _n],
     "zc_ris_mul_base_compress": [_u64p, _u8p, _n],
     "zc_msm": [_u64p, _u64p, _n, _u64p],

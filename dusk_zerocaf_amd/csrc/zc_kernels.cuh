@@ -1142,6 +1142,92 @@ ZC_KERNEL void k_proj_to_extended(const u64* p, u64* out, size_t n)
     pt_store(out + 20 * i, r);
 }
 
+// ---- E-x rows of SURVEY 8(a): coset4 and the ProjectivePoint operations beside add / double
+// FOUR_COSET_GROUP[0..2] (backend/u64/constants.rs:141-183; coset4 never reads entry 3): X and Y limbs, Z = 1, T = 0
+__device__ constexpr u64 FOUR_COSET_XY[3][2][5] = {
+    {{1ull, 0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull, 0ull}},
+    {{2099929430230996ull, 1464742363261928ull, 3309265759432790ull, 2285299817698826ull, 10215362715769ull}, {0ull, 0ull, 0ull, 0ull, 0ull}},
+    {{0ull, 0ull, 0ull, 0ull, 0ull}, {671914833335276ull, 3916664325105025ull, 1367801ull, 0ull, 17592186044416ull}}};
+// EdwardsPoint::coset4 (edwards.rs:603-610): [P, P + C0, P + C1, P + C2] through the unified addition
+ZC_KERNEL void k_ed_coset4(const u64* p, u64* out4, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const pt P = pt_load(p + 20 * i);
+    pt_store(out4 + 80 * i, P);
+    for (int j = 0; j < 3; j++) {
+        u64 x[5], y[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            x[q] = FOUR_COSET_XY[j][0][q];
+            y[q] = FOUR_COSET_XY[j][1][q];
+        }
+        pt C;
+        C.X = mont_to<FP>(fe_from_limbs52(x));
+        C.Y = mont_to<FP>(fe_from_limbs52(y));
+        C.Z = fe_one_m<FP>();
+        C.T = fe_zero();
+        pt_store(out4 + 80 * i + 20 * (j + 1), pt_add(P, C));
+    }
+}
+ZC_KERNEL void k_proj_neg(const u64* p, u64* out, size_t n)                          // edwards.rs:787-807: (-X, Y, Z)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    ppt a = ppt_load(p + 15 * i);
+    a.X = fe_reduce<FP>(fp_neg(a.X));
+    ppt_store(out + 15 * i, a);
+}
+ZC_KERNEL void k_proj_sub(const u64* p, const u64* q, u64* out, size_t n)            // edwards.rs:851-879: self + (-other)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    ppt b = ppt_load(q + 15 * i);
+    b.X = fe_reduce<FP>(fp_neg(b.X));
+    ppt_store(out + 15 * i, proj_add(ppt_load(p + 15 * i), b));
+}
+// ProjectivePoint == (edwards.rs:701-711): equality of the affine images, cross-multiplied; Z = 0 (where the
+// reference's inverse() panics) compares unequal
+ZC_KERNEL void k_proj_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const ppt a = ppt_load(p + 15 * i), b = ppt_load(q + 15 * i);
+    const bool ex = fp_eq(fp_mul(a.X, b.Z), fp_mul(b.X, a.Z));
+    const bool ey = fp_eq(fp_mul(a.Y, b.Z), fp_mul(b.Y, a.Z));
+    eq[i] = (ex && ey && !fp_is_zero(a.Z) && !fp_is_zero(b.Z)) ? 1 : 0;
+}
+ZC_KERNEL void k_proj_is_valid(const u64* p, uint8_t* valid, size_t n)               // edwards.rs:733-748
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    const ppt a = ppt_load(p + 15 * i);
+    pt e;
+    e.X = a.X; e.Y = a.Y; e.Z = a.Z; e.T = fe_zero();
+    valid[i] = ed_is_valid(e) ? 1 : 0;
+}
+// Mul<Scalar> for ProjectivePoint (edwards.rs:881-912) = double_and_add (:102-120) over the projective
+// formulas: Q = (0, 1, 1); while n != 0 { if n odd: Q = Q + N (:809-834); N = N.double() (:915-942, dedicated);
+// n >>= 1 }.  The two formulas differ, so there is no unified step here: one lane per element, the wave
+// runs the addition whenever any lane has its bit set.  Same limbs as the reference (first addition literal).
+ZC_KERNEL void k_proj_scalar_mul(const u64* p, const u64* k, u64* out, size_t n)
+{
+    const size_t i = gid();
+    if (i >= n) return;
+    u64 l[5];
+    load_scalar(l, k + 5 * i);
+    ppt N = ppt_load(p + 15 * i), Q;
+    Q.X = fe_zero();
+    Q.Y = fe_one_m<FP>();
+    Q.Z = fe_one_m<FP>();
+    while ((l[0] | l[1] | l[2] | l[3] | l[4]) != 0) {
+        if (l[0] & 1) Q = proj_add(Q, N);
+        N = proj_double(N);
+        half_without_mod52(l);
+    }
+    ppt_store(out + 15 * i, Q);
+}
+
 // ------------------------------------------------------------------ reduction helper for zc_msm
 // out[i] = in[2i] + in[2i+1] (odd tail copied): pairwise fold of a point array
 ZC_KERNEL void k_ed_fold_pairs(const u64* in, u64* out, size_t n_in)

@@ -1116,6 +1116,41 @@ int zc_proj_to_extended(zc_ctx* ctx, const uint64_t* p, uint64_t* out, size_t n)
         hipLaunchKernelGGL(zc::k_proj_to_extended, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
 }
+// E-x rows: coset4 and the remaining ProjectivePoint operations
+int zc_ed_coset4(zc_ctx* ctx, const uint64_t* p, uint64_t* out4, size_t n)
+{
+    REQUIRE(p); REQUIRE(out4);
+    Arg args[2] = {in_arg(p, 160), out_arg(out4, 640)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_ed_coset4, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
+    });
+}
+int zc_proj_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_proj_neg, p, o, n, 120); }
+int zc_proj_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_proj_sub, nullptr, p, q, o, n, 120); }
+int zc_proj_eq(zc_ctx* ctx, const uint64_t* p, const uint64_t* q, uint8_t* eq, size_t n)
+{
+    REQUIRE(p); REQUIRE(q); REQUIRE(eq);
+    Arg args[3] = {in_arg(p, 120), in_arg(q, 120), out_arg(eq, 1)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_proj_eq, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (uint8_t*)d[2], cnt);
+    });
+}
+int zc_proj_is_valid(zc_ctx* ctx, const uint64_t* p, uint8_t* valid, size_t n)
+{
+    REQUIRE(p); REQUIRE(valid);
+    Arg args[2] = {in_arg(p, 120), out_arg(valid, 1)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_proj_is_valid, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
+    });
+}
+int zc_proj_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
+{
+    REQUIRE(p); REQUIRE(k); REQUIRE(out);
+    Arg args[3] = {in_arg(p, 120), in_arg(k, 40), out_arg(out, 120)};
+    return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_proj_scalar_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
+    });
+}
 
 // ---- fixed-base multiplication of the basepoint
 static int base_table(DevState& D, const zc::u32** table)

@@ -365,6 +365,38 @@ class Engine:
         self._call("zc_proj_to_extended", pp, po, n)
         return out
 
+    # ProjectivePoint beside add / double (edwards.rs:701-748, 787-912) and EdwardsPoint::coset4 (:603-610)
+    def proj_neg(self, p): return self._un("zc_proj_neg", p, 15)
+    def proj_sub(self, p, q): return self._bin("zc_proj_sub", p, q, 15)
+
+    def proj_eq(self, p, q):
+        p, pp, n = self._prep(p, 15, np.uint64)
+        q, pq, _ = self._prep(q, 15, np.uint64)
+        eq, pe = self._alloc(p, n, 0, np.uint8)
+        self._call("zc_proj_eq", pp, pq, pe, n)
+        return eq
+
+    def proj_is_valid(self, p):
+        p, pp, n = self._prep(p, 15, np.uint64)
+        v, pv = self._alloc(p, n, 0, np.uint8)
+        self._call("zc_proj_is_valid", pp, pv, n)
+        return v
+
+    def proj_scalar_mul(self, p, k):
+        p, pp, n = self._prep(p, 15, np.uint64)
+        k, pk, nk = self._prep(k, 5, np.uint64)
+        assert n == nk
+        out, po = self._alloc(p, n, 15, np.uint64)
+        self._call("zc_proj_scalar_mul", pp, pk, po, n)
+        return out
+
+    def ed_coset4(self, p):
+        """coset4: (n, 80) uint64 = four points per input point."""
+        p, pp, n = self._prep(p, 20, np.uint64)
+        out, po = self._alloc(p, n, 80, np.uint64)
+        self._call("zc_ed_coset4", pp, po, n)
+        return out
+
     # ------------------------------------------------------------------ fixed-base (key generation)
     def ed_mul_base(self, k):
         k, pk, n = self._prep(k, 5, np.uint64)

@@ -368,7 +368,52 @@ struct ProjectivePoint {
         Backend::check(zc_proj_to_extended(Backend::ctx(), a, o, 1), "zc_proj_to_extended");
         return EdwardsPoint::unflat(o);
     }
+    static ProjectivePoint identity() { ProjectivePoint r; r.Y.l[0] = 1; r.Z.l[0] = 1; return r; }   // edwards.rs:722-731
+    ProjectivePoint operator-() const                                       // Neg, edwards.rs:787-807
+    {
+        uint64_t a[15], o[15];
+        flat(a);
+        Backend::check(zc_proj_neg(Backend::ctx(), a, o, 1), "zc_proj_neg");
+        return unflat(o);
+    }
+    ProjectivePoint operator-(const ProjectivePoint& q) const               // Sub, edwards.rs:851-879
+    {
+        uint64_t a[15], b[15], o[15];
+        flat(a); q.flat(b);
+        Backend::check(zc_proj_sub(Backend::ctx(), a, b, o, 1), "zc_proj_sub");
+        return unflat(o);
+    }
+    ProjectivePoint operator*(const Scalar& k) const                        // Mul<Scalar>, edwards.rs:881-912
+    {
+        uint64_t a[15], o[15];
+        flat(a);
+        Backend::check(zc_proj_scalar_mul(Backend::ctx(), a, k.l.data(), o, 1), "zc_proj_scalar_mul");
+        return unflat(o);
+    }
+    bool operator==(const ProjectivePoint& q) const                         // edwards.rs:701-711
+    {
+        uint64_t a[15], b[15];
+        uint8_t e = 0;
+        flat(a); q.flat(b);
+        Backend::check(zc_proj_eq(Backend::ctx(), a, b, &e, 1), "zc_proj_eq");
+        return e != 0;
+    }
+    bool is_valid() const                                                   // edwards.rs:733-748
+    {
+        uint64_t a[15];
+        uint8_t v = 0;
+        flat(a);
+        Backend::check(zc_proj_is_valid(Backend::ctx(), a, &v, 1), "zc_proj_is_valid");
+        return v != 0;
+    }
 };
+inline std::array<EdwardsPoint, 4> coset4(const EdwardsPoint& p)             // EdwardsPoint::coset4, edwards.rs:603-610
+{
+    uint64_t a[20], o[80];
+    p.flat(a);
+    Backend::check(zc_ed_coset4(Backend::ctx(), a, o, 1), "zc_ed_coset4");
+    return {EdwardsPoint::unflat(o), EdwardsPoint::unflat(o + 20), EdwardsPoint::unflat(o + 40), EdwardsPoint::unflat(o + 60)};
+}
 
 struct CompressedEdwardsY {
     std::array<uint8_t, 32> bytes{};

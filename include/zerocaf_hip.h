@@ -192,6 +192,17 @@ int zc_ris_from_uniform_bytes(zc_ctx *ctx, const uint8_t *in64, uint64_t *out, s
 int zc_proj_add(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
 int zc_proj_double(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
 int zc_proj_to_extended(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+/* Neg src/edwards.rs:787-807   Sub :851-879 (self + (-other))   == :701-711 (affine images; Z = 0, where the
+ * reference's inverse() panics, compares unequal)   is_valid :733-748
+ * Mul<Scalar> :881-912 = double_and_add :102-120 over the projective Add / dedicated Double, identity (0, 1, 1) */
+int zc_proj_neg(zc_ctx *ctx, const uint64_t *p, uint64_t *out, size_t n);
+int zc_proj_sub(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
+int zc_proj_eq(zc_ctx *ctx, const uint64_t *p, const uint64_t *q, uint8_t *eq, size_t n);
+int zc_proj_is_valid(zc_ctx *ctx, const uint64_t *p, uint8_t *valid, size_t n);
+int zc_proj_scalar_mul(zc_ctx *ctx, const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n);
+/* EdwardsPoint::coset4: src/edwards.rs:603-610 with FOUR_COSET_GROUP (backend/u64/constants.rs:141-189):
+ * out4 = n x 4 points [P, P + C0, P + C1, P + C2], each sum the unified addition :465-489 */
+int zc_ed_coset4(zc_ctx *ctx, const uint64_t *p, uint64_t *out4, size_t n);
 
 /* Fixed-base multiplication of BASEPOINT (constants.rs:188-211) with a precomputed comb table:
  * the correct counterpart of the reference's window_naf_mul (src/edwards.rs:155-171, which

@@ -641,6 +641,43 @@ impl HipBackend {
         Ok(unflat_ed(&self.un(ffi::zc_proj_to_extended, &flat_proj(p), p.len(), 20)?))
     }
 
+    /// `-p` (`:787-807`).
+    pub fn proj_neg(&self, p: &[ProjectivePoint]) -> Result<Vec<ProjectivePoint>> {
+        Ok(unflat_proj(&self.un(ffi::zc_proj_neg, &flat_proj(p), p.len(), 15)?))
+    }
+
+    /// `p - q` (`:851-879`).
+    pub fn proj_sub(&self, p: &[ProjectivePoint], q: &[ProjectivePoint]) -> Result<Vec<ProjectivePoint>> {
+        assert_eq!(p.len(), q.len());
+        Ok(unflat_proj(&self.bin(ffi::zc_proj_sub, &flat_proj(p), &flat_proj(q), p.len(), 15)?))
+    }
+
+    /// `p == q` (`:701-711`).
+    pub fn proj_eq(&self, p: &[ProjectivePoint], q: &[ProjectivePoint]) -> Result<Vec<bool>> {
+        assert_eq!(p.len(), q.len());
+        let (fp, fq, n) = (flat_proj(p), flat_proj(q), p.len());
+        let mut eq = vec![0u8; n];
+        check(unsafe { ffi::zc_proj_eq(self.ctx, fp.as_ptr(), fq.as_ptr(), eq.as_mut_ptr(), n) })?;
+        Ok(flags(eq))
+    }
+
+    /// `p.is_valid()` (`:733-748`).
+    pub fn proj_is_valid(&self, p: &[ProjectivePoint]) -> Result<Vec<bool>> {
+        Ok(flags(self.flag(ffi::zc_proj_is_valid, &flat_proj(p), p.len())?))
+    }
+
+    /// `&p * &k` (`:881-912`).
+    pub fn proj_scalar_mul(&self, p: &[ProjectivePoint], k: &[Scalar]) -> Result<Vec<ProjectivePoint>> {
+        assert_eq!(p.len(), k.len());
+        Ok(unflat_proj(&self.bin(ffi::zc_proj_scalar_mul, &flat_proj(p), &flat_sc(k), p.len(), 15)?))
+    }
+
+    /// `p.coset4()` (`:603-610`).
+    pub fn ed_coset4(&self, p: &[EdwardsPoint]) -> Result<Vec<[EdwardsPoint; 4]>> {
+        let out = unflat_ed(&self.un(ffi::zc_ed_coset4, &flat_ed(p), p.len(), 80)?);
+        Ok(out.chunks_exact(4).map(|c| [c[0], c[1], c[2], c[3]]).collect())
+    }
+
     // -------------------------------------------------------------- Ristretto (src/ristretto.rs)
     /// `p.compress()` (`:398-425`).
     pub fn ris_compress(&self, p: &[RistrettoPoint]) -> Result<Vec<CompressedRistretto>> {

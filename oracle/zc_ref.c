@@ -1203,6 +1203,84 @@ void zr_ris_roundtrip_mul_batch(const uint8_t *in, const uint64_t *k, uint8_t *o
         if (ok) ok[i] = (uint8_t)o;
     }
 }
+/* ------------------------------------------------------------------ rows beside the path (SURVEY 8a E-x) */
+/* FOUR_COSET_GROUP[0..2], backend/u64/constants.rs:141-183 (coset4 never reads entry 3) */
+static const zr_pt ZR_FOUR_COSET[3] = {
+    {{{1ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{0ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{1ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{0ULL, 0ULL, 0ULL, 0ULL, 0ULL}}},
+    {{{2099929430230996ULL, 1464742363261928ULL, 3309265759432790ULL, 2285299817698826ULL, 10215362715769ULL}}, {{0ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{1ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{0ULL, 0ULL, 0ULL, 0ULL, 0ULL}}},
+    {{{0ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{671914833335276ULL, 3916664325105025ULL, 1367801ULL, 0ULL, 17592186044416ULL}}, {{1ULL, 0ULL, 0ULL, 0ULL, 0ULL}}, {{0ULL, 0ULL, 0ULL, 0ULL, 0ULL}}}
+};
+/* E:603-610: [P, P + C0, P + C1, P + C2] through the unified addition E:465-489 */
+void zr_ed_coset4(zr_pt r[4], const zr_pt *p)
+{
+    const zr_pt in = *p;
+    r[0] = in;
+    for (int j = 0; j < 3; j++) zr_ed_add(&r[j + 1], &in, &ZR_FOUR_COSET[j]);
+}
+/* E:787-807: (-X, Y, Z) */
+void zr_proj_neg(zr_fe r[3], const zr_fe p[3])
+{
+    zr_fe x;
+    zr_fe_neg(&x, &p[0]);
+    r[0] = x; r[1] = p[1]; r[2] = p[2];
+}
+/* E:851-879: self + (-other) */
+void zr_proj_sub(zr_fe r[3], const zr_fe p[3], const zr_fe q[3])
+{
+    zr_fe nq[3];
+    zr_proj_neg(nq, q);
+    zr_proj_add(r, p, nq);
+}
+/* E:701-711: both sides to AffinePoint (E:1094-1110: X/Z, Y/Z; inverse() panics for Z = 0 -> -1), then E:1044-1048 */
+int zr_proj_eq(const zr_fe p[3], const zr_fe q[3])
+{
+    zr_fe zi, x1, y1, x2, y2;
+    if (!zr_fe_inverse(&zi, &p[2])) return -1;
+    zr_fe_mul(&x1, &p[0], &zi);
+    zr_fe_mul(&y1, &p[1], &zi);
+    if (!zr_fe_inverse(&zi, &q[2])) return -1;
+    zr_fe_mul(&x2, &q[0], &zi);
+    zr_fe_mul(&y2, &q[1], &zi);
+    return limbs_eq(&x1, &x2) & limbs_eq(&y1, &y2);
+}
+/* E:733-748: (aX^2 + Y^2) Z^2 == Z^4 + d X^2 Y^2 */
+int zr_proj_is_valid(const zr_fe p[3])
+{
+    zr_pt e;
+    e.X = p[0]; e.Y = p[1]; e.Z = p[2]; e.T = FE_ZERO;
+    return zr_ed_is_valid(&e);                                /* E:393-400 delegates to this very check */
+}
+/* E:881-912 -> double_and_add E:102-120 with T = ProjectivePoint: identity (0, 1, 1) E:722-731,
+ * Add E:809-834, dedicated Double E:915-942 */
+void zr_proj_scalar_mul(zr_fe r[3], const zr_fe p[3], const zr_sc *k)
+{
+    zr_fe N[3] = {p[0], p[1], p[2]}, Q[3] = {FE_ZERO, FE_ONE, FE_ONE};
+    zr_sc n = *k;
+    while (!limbs_eq(&n, &FE_ZERO)) {
+        if (!zr_sc_is_even(&n)) zr_proj_add(Q, Q, N);
+        zr_proj_double(N, N);
+        limbs_half_without_mod(&n, &n);
+    }
+    r[0] = Q[0]; r[1] = Q[1]; r[2] = Q[2];
+}
+void zr_ed_coset4_batch(const uint64_t *p, uint64_t *out4, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_ed_coset4((zr_pt *)(out4 + 80 * i), PT(p, i)); }
+void zr_proj_neg_batch(const uint64_t *p, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_proj_neg((zr_fe *)(out + 15 * i), (const zr_fe *)(p + 15 * i)); }
+void zr_proj_sub_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_proj_sub((zr_fe *)(out + 15 * i), (const zr_fe *)(p + 15 * i), (const zr_fe *)(q + 15 * i)); }
+void zr_proj_eq_batch(const uint64_t *p, const uint64_t *q, uint8_t *eq, uint8_t *ok, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        const int e = zr_proj_eq((const zr_fe *)(p + 15 * i), (const zr_fe *)(q + 15 * i));
+        eq[i] = (uint8_t)(e == 1);
+        if (ok) ok[i] = (uint8_t)(e >= 0);
+    }
+}
+void zr_proj_is_valid_batch(const uint64_t *p, uint8_t *valid, size_t n)
+{ for (size_t i = 0; i < n; i++) valid[i] = (uint8_t)zr_proj_is_valid((const zr_fe *)(p + 15 * i)); }
+void zr_proj_scalar_mul_batch(const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n)
+{ for (size_t i = 0; i < n; i++) zr_proj_scalar_mul((zr_fe *)(out + 15 * i), (const zr_fe *)(p + 15 * i), FE(k, i)); }
 void zr_proj_add_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n)
 { for (size_t i = 0; i < n; i++) zr_proj_add((zr_fe *)(out + 15 * i), (const zr_fe *)(p + 15 * i), (const zr_fe *)(q + 15 * i)); }
 void zr_proj_double_batch(const uint64_t *p, uint64_t *out, size_t n)

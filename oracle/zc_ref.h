@@ -157,6 +157,18 @@ void zr_proj_double(zr_fe r[3], const zr_fe p[3]);
 void zr_proj_to_extended(zr_pt *r, const zr_fe p[3]);
 int  zr_ris_is_valid(const zr_pt *p);
 void zr_ris_from_uniform_bytes(zr_pt *r, const uint8_t b[64]);
+void zr_ed_coset4(zr_pt r[4], const zr_pt *p);
+void zr_proj_neg(zr_fe r[3], const zr_fe p[3]);
+void zr_proj_sub(zr_fe r[3], const zr_fe p[3], const zr_fe q[3]);
+int  zr_proj_eq(const zr_fe p[3], const zr_fe q[3]);
+int  zr_proj_is_valid(const zr_fe p[3]);
+void zr_proj_scalar_mul(zr_fe r[3], const zr_fe p[3], const zr_sc *k);
+void zr_ed_coset4_batch(const uint64_t *p, uint64_t *out4, size_t n);
+void zr_proj_neg_batch(const uint64_t *p, uint64_t *out, size_t n);
+void zr_proj_sub_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
+void zr_proj_eq_batch(const uint64_t *p, const uint64_t *q, uint8_t *eq, uint8_t *ok, size_t n);
+void zr_proj_is_valid_batch(const uint64_t *p, uint8_t *valid, size_t n);
+void zr_proj_scalar_mul_batch(const uint64_t *p, const uint64_t *k, uint64_t *out, size_t n);
 void zr_proj_add_batch(const uint64_t *p, const uint64_t *q, uint64_t *out, size_t n);
 void zr_proj_double_batch(const uint64_t *p, uint64_t *out, size_t n);
 void zr_proj_to_extended_batch(const uint64_t *p, uint64_t *out, size_t n);

@@ -282,6 +282,38 @@ def ris_roundtrip_mul(b, k):
 
 proj_add = _binop("zr_proj_add_batch", 15)
 proj_double = _unop("zr_proj_double_batch", 15)
+proj_neg = _unop("zr_proj_neg_batch", 15)
+proj_sub = _binop("zr_proj_sub_batch", 15)
+
+
+def proj_eq(p, q):
+    """(eq, ok): ok = 0 where the reference's inverse() would panic (Z = 0)."""
+    p, q = _u64(p, 15), _u64(q, 15)
+    eq = np.empty(p.shape[0], dtype=np.uint8)
+    ok = np.empty(p.shape[0], dtype=np.uint8)
+    lib().zr_proj_eq_batch(_p(p), _p(q), _p(eq), _p(ok), C.c_size_t(p.shape[0]))
+    return eq, ok
+
+
+def proj_is_valid(p):
+    p = _u64(p, 15)
+    v = np.empty(p.shape[0], dtype=np.uint8)
+    lib().zr_proj_is_valid_batch(_p(p), _p(v), C.c_size_t(p.shape[0]))
+    return v
+
+
+def proj_scalar_mul(p, k):
+    p, k = _u64(p, 15), _u64(k, 5)
+    out = np.empty_like(p)
+    lib().zr_proj_scalar_mul_batch(_p(p), _p(k), _p(out), C.c_size_t(p.shape[0]))
+    return out
+
+
+def ed_coset4(p):
+    p = _u64(p, 20)
+    out = np.empty((p.shape[0], 80), dtype=np.uint64)
+    lib().zr_ed_coset4_batch(_p(p), _p(out), C.c_size_t(p.shape[0]))
+    return out
 
 
 def proj_to_extended(p):

@@ -106,6 +106,21 @@ def odd_multiples_table():
     return {"points": pts, "cite": "%s:%d" % (path, line_of(text, start))}
 
 
+def four_coset_group():
+    """FOUR_COSET_GROUP: [EdwardsPoint; 4] (what EdwardsPoint::coset4 adds, src/edwards.rs:603-610)."""
+    path = "src/backend/u64/constants.rs"
+    text = open(os.path.join(REF, path)).read()
+    start = text.index("FOUR_COSET_GROUP")
+    body = text[start:text.index("];", start)]
+    pts = []
+    for m in re.finditer(
+        r"X:\s*FieldElement\(%s\)\s*,\s*Y:\s*FieldElement\(%s\)\s*,\s*Z:\s*FieldElement\(%s\)\s*,\s*T:\s*FieldElement\(%s\)"
+        % (NUM5, NUM5, NUM5, NUM5), body, re.S):
+        g = [int(x) for x in m.groups()]
+        pts.append([g[0:5], g[5:10], g[10:15], g[15:20]])
+    return {"points": pts, "cite": "%s:%d" % (path, line_of(text, start))}
+
+
 def hex_strings(path, lo, hi):
     text = open(os.path.join(REF, path)).read()
     out = []
@@ -137,6 +152,7 @@ def main():
         "ristretto_elligator_hex": hex_strings("src/ristretto.rs", 700, 715),
         "ristretto_elligator_point": inline_limb_arrays("src/ristretto.rs", 683, 706),
         "odd_multiples_table": odd_multiples_table(),
+        "four_coset_group": four_coset_group(),
     }
     # scalar constants that are `pub const fn`-style or inline in tests
     with open(OUT, "w") as f:

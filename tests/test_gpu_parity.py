@@ -106,6 +106,47 @@ def test_scalar_rows_beside_the_path_half_pow_shr_bits_naf(eng, oracle, kats):
     assert eq(got, want) and eq(sq, wsq) and 0 < sq.sum() < n
 
 
+def test_rows_beside_the_path_coset4_and_projective(eng, oracle, kats):
+    """SURVEY 8(a) row E-x on the GPU: coset4 and ProjectivePoint Neg / Sub / == / is_valid / Mul<Scalar>,
+    limb-exact vs the oracle (reference KAT points, then bulk incl. raw scalars above 2^256 and Z = 0)."""
+    c = lambda name: kats["edwards_points"][name]["coords"]
+    pj = lambda name: np.array([c(name)["X"] + c(name)["Y"] + c(name).get("Z", [1, 0, 0, 0, 0])], dtype=np.uint64)
+    p1, p2, p4 = pj("P1_PROJECTIVE"), pj("P2_PROJECTIVE"), pj("P4_PROJECTIVE")
+    eight = np.array([[8, 0, 0, 0, 0]], dtype=np.uint64)
+    d3 = eng.proj_double(eng.proj_double(eng.proj_double(p1)))
+    assert eng.proj_eq(eng.proj_scalar_mul(p1, eight), d3).tolist() == [1]            # edwards.rs:1484-1492
+    assert eng.proj_is_valid(p2).tolist() == [1] and eng.proj_eq(eng.proj_sub(p4, p2), p1).tolist() == [1]
+    n = 1500 + 3
+    E = V.base_multiples(oracle, n, V.SEED + 170)
+    rng = np.random.default_rng(V.SEED + 171)
+    # projective images with non-trivial Z: (X, Y, Z) of r*B, and of s*B for the second operand
+    P = np.ascontiguousarray(E[:, :15])
+    Q = np.ascontiguousarray(np.roll(E, 7, axis=0)[:, :15])
+    assert eq(eng.proj_neg(P), oracle.proj_neg(P))
+    assert eq(eng.proj_sub(P, Q), oracle.proj_sub(P, Q))
+    same = np.ascontiguousarray(oracle.proj_add(P, Q))
+    diff = same.copy()
+    diff[::3] = P[::3]
+    diff[5, 10:15] = 0                                                               # Z = 0: reference panics -> unequal
+    got = eng.proj_eq(same, diff)
+    weq, wok = oracle.proj_eq(same, diff)
+    assert eq(got, weq & wok) and got[5] == 0 and 0 < got.sum() < n
+    v = P.copy()
+    v[::4, 0] ^= np.uint64(1)                                                        # off the curve
+    assert eq(eng.proj_is_valid(v), oracle.proj_is_valid(v)) and 0 < eng.proj_is_valid(v).sum() < n
+    K = V.rand_scalars_np(n, V.SEED + 172, bits=252)
+    _edge_scalars(K)
+    raw = V.raw_scalar_edges()
+    K[-len(raw):] = raw
+    m = 600
+    assert eq(eng.proj_scalar_mul(P[:m], K[:m]), oracle.mt(oracle.proj_scalar_mul, P[:m], K[:m]))
+    assert eq(eng.proj_scalar_mul(P[-len(raw):], K[-len(raw):]), oracle.proj_scalar_mul(P[-len(raw):], K[-len(raw):]))
+    E[3] = V.IDENT_ROW
+    got4 = eng.ed_coset4(E)
+    assert eq(got4, oracle.ed_coset4(E))
+    assert eng.ris_eq(np.ascontiguousarray(got4[:, 20:40]), E).all()                # four_coset_eq_basepoint's property
+
+
 def test_kat_edwards_and_ristretto(eng, kats):
     def ept(name):
         c = kats["edwards_points"][name]["coords"]

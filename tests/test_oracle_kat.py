@@ -516,3 +516,53 @@ def test_scalar_mul_raw_patterns_vs_model(oracle):
     assert np.array_equal(got, want)
     assert np.array_equal(got[0], np.array(V.IDENT_ROW, dtype=np.uint64))             # [0,0,0,0,1<<50]
     assert np.array_equal(got[1], V.pts_np([pm.ed_add(pm.IDENT, pts[1])])[0])           # [1,0,0,0,1<<50]
+
+
+def test_rows_beside_the_path_coset4_and_projective(oracle, kats):
+    """SURVEY 8(a) row E-x: EdwardsPoint::coset4 and ProjectivePoint Neg / Sub / == / is_valid / Mul<Scalar>,
+    pinned by the reference's own assertions on them."""
+    pj = lambda name: np.array([sum(ept(kats, name)[:3], [])], dtype=np.uint64)
+    ident3 = np.array([ZERO + ONE + ONE], dtype=np.uint64)
+    # projective_coords_neg_identity / projective_point_neg (edwards.rs:1450-1467)
+    assert oracle.proj_eq(oracle.proj_neg(ident3), ident3)[0].tolist() == [1]
+    # projective_double_and_add (edwards.rs:1484-1492): P1 * 8 == P1.double().double().double(), limb for limb
+    p1 = pj("P1_PROJECTIVE")
+    d3 = oracle.proj_double(oracle.proj_double(oracle.proj_double(p1)))
+    eight = np.array([[8, 0, 0, 0, 0]], dtype=np.uint64)
+    assert oracle.proj_eq(oracle.proj_scalar_mul(p1, eight), d3)[0].tolist() == [1]
+    # ... and the sequence is double_and_add's: Q = identity + 8P1 at the last step
+    assert np.array_equal(oracle.proj_scalar_mul(p1, eight), oracle.proj_add(ident3, d3))
+    # validity_check (edwards.rs:1578-1590) and == through the affine images (affine_point_eq :1541-1546)
+    assert oracle.proj_is_valid(pj("P2_PROJECTIVE")).tolist() == [1]
+    bad = pj("P2_PROJECTIVE").copy()
+    bad[0, 0] ^= 1
+    assert oracle.proj_is_valid(bad).tolist() == [0]
+    assert oracle.proj_eq(pj("P3_PROJECTIVE"), oracle.proj_double(p1))[0].tolist() == [1]
+    assert oracle.proj_eq(pj("P4_PROJECTIVE"), oracle.proj_add(p1, pj("P2_PROJECTIVE")))[0].tolist() == [1]
+    assert oracle.proj_eq(pj("P4_PROJECTIVE"), p1)[0].tolist() == [0]
+    # Sub = self + (-other): P4 - P2 == P1 as points
+    assert oracle.proj_eq(oracle.proj_sub(pj("P4_PROJECTIVE"), pj("P2_PROJECTIVE")), p1)[0].tolist() == [1]
+    # Z = 0: the reference's inverse() panics -> ok = 0
+    z0 = p1.copy()
+    z0[0, 10:15] = 0
+    assert oracle.proj_eq(z0, p1)[1].tolist() == [0]
+    # the projective ladder agrees with the extended one as a point, for a full-size scalar
+    k = V.rand_scalars_np(1, V.SEED + 160, bits=249)
+    ext = oracle.proj_to_extended(p1)
+    via_proj = oracle.proj_to_extended(oracle.proj_scalar_mul(p1, k))
+    assert oracle.ed_eq(via_proj, oracle.ed_scalar_mul(ext, k)).tolist() == [1]
+    # coset4: constants as the reference holds them; four_coset_eq_basepoint (ristretto.rs:633-641):
+    # every coset point is the same RistrettoPoint; decompress_id (:581-593): the identity's coset holds
+    # a point that compresses to CompressedEdwardsY::identity()
+    coset_consts = kats["four_coset_group"]["points"]
+    base = np.array([sum(pm.pt_limbs(pm.BASEPOINT), [])], dtype=np.uint64)
+    c4 = oracle.ed_coset4(base).reshape(4, 20)
+    assert np.array_equal(c4[0], base[0])
+    for j in range(3):
+        cj = np.array([sum(coset_consts[j], [])], dtype=np.uint64)
+        assert np.array_equal(c4[j + 1], oracle.ed_add(base, cj)[0])
+    assert oracle.ris_eq(c4, np.tile(base, (4, 1))).tolist() == [1, 1, 1, 1]
+    ident = np.array([V.IDENT_ROW], dtype=np.uint64)
+    enc, ok = oracle.ed_compress(oracle.ed_coset4(ident).reshape(4, 20))
+    ident_enc = bytes([1] + [0] * 31)                                # edwards.rs:273-283
+    assert any(o == 1 and bytes(e.tolist()) == ident_enc for e, o in zip(enc, ok))
