@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KT = [("scalar_mul", "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 3 --cpu-sample 0` "
                      "(strict scalar-mul, 2^20 per launch; inputs come from k_ed_mul_base)"),
       ("ristretto", "`... --workload ristretto --units 4194304 --steps 5 --warmup 1` (fused decompress -> scalar-mul -> compress on the "
-                    "windowed core, 2^22 per call = 6 chunk launches alternating between two streams; inputs come from k_ed_mul_base + k_ris_compress)"),
+                    "windowed core, 2^22 per call = one launch over the 256 MB table ring; inputs come from k_ed_mul_base + k_ris_compress)"),
       ("msm_2p21", "`... --workload msm --units 2097152 --steps 5 --warmup 1` (bucket method, 2^21 pairs per call: the per-GPU shard of BASELINE configs[4])"),
       ("msm_2p24", "`... --workload msm --units 16777216 --steps 3 --warmup 1` (2^24 pairs on one GPU)"),
       ("fe_mul", "`... --workload fe_mul --units 16777216 --steps 20 --warmup 30` (2^24 elements, 2.0 GB per launch; the long warm-up "
@@ -25,7 +25,7 @@ KT = [("scalar_mul", "`rocprofv3 --kernel-trace --stats -- python bench.py --ste
 
 
 DOMINANT = {"scalar_mul": "k_ed_scalar_mul", "ristretto": "k_ris_roundtrip_mul_fast", "fe_mul": "k_fe_mul"}
-WARMUP = {"scalar_mul": 3, "ristretto": 6, "fe_mul": 30}
+WARMUP = {"scalar_mul": 3, "ristretto": 1, "fe_mul": 30}
 CALLS = {"msm_2p21": 6, "msm_2p24": 4}
 
 
