@@ -83,8 +83,212 @@ ZC_DI bool fp_is_zero(const fe& a) { return fe_is_zero_canon(fp_canon(a)); }
 // a == b (mod p); b must be R-class
 ZC_DI bool fp_eq(const fe& a, const fe& b) { return fp_is_zero(fp_sub(a, b)); }
 
-// a^(p-2): same value as the reference's Savas-Koc inverse (field.rs:854-925) for a != 0
-ZC_DI fe fp_invert(const fe& a) { return fp_pow_inv(a); }
+// ---------------------------------------------------------------- modular inverse by division steps
+// a^-1 mod N through Bernstein-Yang division steps ("safegcd", the half-delta variant with its fixed
+// schedule): 20 rounds of 30 division steps on the low words of (f, g) = (N, a), each round followed by
+// one 2x2 integer matrix applied to the full-width (f, g) and, modulo N, to (d, e) = (0, 1); after 600
+// steps (590 suffice for 256-bit operands) g = 0, f = +-1 and d = +-a^-1.  Signed 30-bit limbs in
+// 32-bit registers; a round costs ~350 32-bit ALU instructions and ~110 multiplier-class ones (signed
+// 32 x 32 + 64 multiply-accumulates), i.e. an inversion costs about as much as 45 field
+// multiplications where the Fermat power a^(N-2) costs 290 -- and its dependent chain is as much
+// shorter, which is what bounds a launch of one wave per SIMD.  Uniform control flow (no lane ever
+// leaves the schedule); a = 0 returns 0, like a^(N-2).  Same value as the reference's Savas-Koc
+// inverse (field.rs:854-925): the inverse is unique.
+constexpr int32_t M30 = 0x3fffffff;
+struct sgcd_mat {
+    int32_t u, v, q, r;
+};
+// 30 division steps on the low 32 bits of f (odd) and g; returns the new zeta and the matrix t with
+// t * [f, g] = 2^30 * [f', g']
+ZC_DI int32_t sgcd_divsteps30(int32_t zeta, u32 f, u32 g, sgcd_mat& t)
+{
+    u32 u = 1, v = 0, q = 0, r = 1;
+#pragma unroll 6
+    for (int i = 0; i < 30; i++) {
+        u32 mask1 = (u32)(zeta >> 31);                         // zeta < 0
+        const u32 mask2 = 0u - (g & 1u);                       // g odd
+        const u32 x = (f ^ mask1) - mask1, y = (u ^ mask1) - mask1, z = (v ^ mask1) - mask1;
+        g += x & mask2;
+        q += y & mask2;
+        r += z & mask2;
+        mask1 &= mask2;
+        zeta = (int32_t)((u32)zeta ^ mask1) - 1;
+        f += g & mask1;
+        u += q & mask1;
+        v += r & mask1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return zeta;
+}
+// A 32-bit value the optimiser knows nothing about any more: without it the compiler remembers that a
+// masked limb is a zero-extended 30-bit quantity and multiplies it as 64 x 64 (one unsigned
+// multiply-accumulate plus two v_mul_lo_u32 and an add) instead of one signed v_mad_i64_i32.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZC_PIN32(x) asm("" : "+v"(x))
+#else
+#define ZC_PIN32(x) asm("" : "+r"(x))
+#endif
+// the modulus in 30-bit limbs, as compile-time constants (N = 2^k + c: limbs 5..7 are zero)
+template <class F>
+struct sgcd_mod {
+    static constexpr int32_t limb(int j)
+    {
+        const int s = 30 * j, idx = s / 29, off = s % 29;
+        u64 w = idx < 9 ? (u64)F::N[idx] >> off : 0;
+        if (idx + 1 < 9) w |= (u64)F::N[idx + 1] << (29 - off);
+        if (idx + 2 < 9) w |= (u64)F::N[idx + 2] << (58 - off);
+        return (int32_t)(w & 0x3fffffffu);
+    }
+};
+// (f, g) <- t * (f, g) / 2^30 (exact)
+ZC_DI void sgcd_update_fg(int32_t (&f)[9], int32_t (&g)[9], const sgcd_mat& t)
+{
+    int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
+    int64_t cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
+        cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
+        f[i - 1] = (int32_t)cf & M30;
+        g[i - 1] = (int32_t)cg & M30;
+        ZC_PIN32(f[i - 1]);
+        ZC_PIN32(g[i - 1]);
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f[8] = (int32_t)cf;
+    g[8] = (int32_t)cg;
+    ZC_PIN32(f[8]);
+    ZC_PIN32(g[8]);
+}
+// (d, e) <- t * (d, e) / 2^30 mod N, both kept in (-2N, N): a multiple of N makes the low 30 bits vanish
+template <class F, int I>
+ZC_DI void sgcd_de_limb(int32_t (&d)[9], int32_t (&e)[9], const sgcd_mat& t, int32_t md, int32_t me, int64_t& cd, int64_t& ce)
+{
+    constexpr int32_t mi = sgcd_mod<F>::limb(I);
+    cd += (int64_t)t.u * d[I] + (int64_t)t.v * e[I];
+    ce += (int64_t)t.q * d[I] + (int64_t)t.r * e[I];
+    if constexpr (mi != 0) {
+        cd += (int64_t)mi * md;
+        ce += (int64_t)mi * me;
+    }
+    d[I - 1] = (int32_t)cd & M30;
+    e[I - 1] = (int32_t)ce & M30;
+    ZC_PIN32(d[I - 1]);
+    ZC_PIN32(e[I - 1]);
+    cd >>= 30;
+    ce >>= 30;
+    if constexpr (I < 8) sgcd_de_limb<F, I + 1>(d, e, t, md, me, cd, ce);
+}
+template <class F>
+ZC_DI void sgcd_update_de(int32_t (&d)[9], int32_t (&e)[9], const sgcd_mat& t, u32 m_inv30)
+{
+    constexpr int32_t m0 = sgcd_mod<F>::limb(0);
+    const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+    int32_t md = (t.u & sd) + (t.v & se);
+    int32_t me = (t.q & sd) + (t.r & se);
+    int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
+    int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
+    md -= (int32_t)((m_inv30 * (u32)cd + (u32)md) & (u32)M30);
+    me -= (int32_t)((m_inv30 * (u32)ce + (u32)me) & (u32)M30);
+    ZC_PIN32(md);
+    ZC_PIN32(me);
+    cd += (int64_t)m0 * md;
+    ce += (int64_t)m0 * me;
+    cd >>= 30;
+    ce >>= 30;
+    sgcd_de_limb<F, 1>(d, e, t, md, me, cd, ce);
+    d[8] = (int32_t)cd;
+    e[8] = (int32_t)ce;
+    ZC_PIN32(d[8]);
+    ZC_PIN32(e[8]);
+}
+// nine 29-bit limbs (canonical value) -> nine 30-bit limbs and back
+ZC_DI void sgcd_pack30(int32_t (&o)[9], const fe& c)
+{
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int s = 30 * j, idx = s / 29, off = s % 29;
+        u64 w = idx < 9 ? (u64)c.v[idx] >> off : 0;
+        if (idx + 1 < 9) w |= (u64)c.v[idx + 1] << (29 - off);
+        if (idx + 2 < 9) w |= (u64)c.v[idx + 2] << (58 - off);
+        o[j] = (int32_t)(w & (u64)M30);
+    }
+}
+ZC_DI fe sgcd_unpack30(const int32_t (&d)[9])
+{
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int s = 29 * i, idx = s / 30, off = s % 30;
+        u64 w = (u64)(u32)d[idx] >> off;
+        if (idx + 1 < 9) w |= (u64)(u32)d[idx + 1] << (30 - off);
+        r.v[i] = (u32)w & M29;
+    }
+    return r;
+}
+// plain canonical a (< N) -> plain canonical a^-1 mod N (0 for a = 0)
+template <class F>
+ZC_DI fe fe_inverse_divsteps(const fe& a)
+{
+    int32_t f[9], g[9], d[9], e[9];
+    sgcd_pack30(g, a);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        f[i] = sgcd_mod<F>::limb(i);
+        d[i] = 0;
+        e[i] = 0;
+    }
+    e[0] = 1;
+    // N^-1 mod 2^30 from -N^-1 mod 2^29 (F::NP) by one Newton step
+    constexpr u32 n0 = (u32)sgcd_mod<F>::limb(0) | ((u32)sgcd_mod<F>::limb(1) << 30);
+    u32 inv = 0u - F::NP;
+    inv *= 2u - n0 * inv;
+    const u32 m_inv30 = inv & (u32)M30;
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int round = 0; round < 20; round++) {
+        sgcd_mat t;
+        zeta = sgcd_divsteps30(zeta, (u32)f[0] | ((u32)f[1] << 30), (u32)g[0] | ((u32)g[1] << 30), t);
+        sgcd_update_de<F>(d, e, t, m_inv30);
+        sgcd_update_fg(f, g, t);
+    }
+    // d = +-a^-1 in (-2N, N) with the sign of f: add N if negative, negate if f < 0, add N again if negative
+    const int32_t neg = f[8] >> 31;
+    int32_t add = d[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = ((d[i] + (sgcd_mod<F>::limb(i) & add)) ^ neg) - neg;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        d[i + 1] += d[i] >> 30;
+        d[i] &= M30;
+    }
+    add = d[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] += sgcd_mod<F>::limb(i) & add;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        d[i + 1] += d[i] >> 30;
+        d[i] &= M30;
+    }
+    return sgcd_unpack30(d);
+}
+
+// a^-1 in the Montgomery domain (a R -> a^-1 R; 0 -> 0): same value as the reference's Savas-Koc
+// inverse (field.rs:854-925) and as a^(p-2) (fp_pow_inv, kept for the A/B: -DZC_INVERT_FERMAT)
+ZC_DI fe fp_invert(const fe& a)
+{
+#ifdef ZC_INVERT_FERMAT
+    return fp_pow_inv(a);
+#else
+    return mont_to<FP>(fe_inverse_divsteps<FP>(fp_canon(a)));
+#endif
+}
 
 // |x| by the reference's sign rule: negate when canonical value > (p-1)/2
 // (field.rs:552-557 + subtle conditional_negate).  Returns R-class Montgomery value.
@@ -156,31 +360,35 @@ ZC_DI void store5(u64* __restrict__ p, const u64 (&l)[5])
 
 ZC_DI bool limbs52_all_zero(const u64 (&l)[5]) { return (l[0] | l[1] | l[2] | l[3] | l[4]) == 0; }
 
-// One lane's share of the batched inversion (Montgomery's trick over `c` consecutive
-// elements starting at `lo`; see k_fe_invert_chunked in zc_kernels.cuh).
+// plain inverse of a register value (R-class, i.e. < 3N): acc -> acc^-1 mod N, no Montgomery factor
+ZC_DI fe fp_inverse_of_register(const fe& acc) { return fe_inverse_divsteps<FP>(fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(acc))); }
+
+// One lane's share of the batched inversion (Montgomery's trick over the up to `c` elements
+// lo, lo + stride, lo + 2 stride, ...; see k_fe_invert_chunked in zc_kernels.cuh: stride = number of
+// lanes, so that the lanes of a wave touch neighbouring records in every pass).
 // `num` != nullptr turns it into a batched division: out_j = num_j / a_j (Div, field.rs:277-300).
-ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, int c, const u64* num = nullptr)
+ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, size_t stride, int c, const u64* num = nullptr)
 {
-    const int cnt = (int)((n - lo < (size_t)c) ? (n - lo) : (size_t)c);
+    const size_t avail = (n - lo + stride - 1) / stride;
+    const int cnt = (int)(avail < (size_t)c ? avail : (size_t)c);
     const fe neutral = fe_one_m<FP>();
     fe acc = neutral;
     for (int j = 0; j < cnt; j++) {
         u64 l[5];
-        load5(l, a + 5 * (lo + j));
+        load5(l, a + 5 * (lo + (size_t)j * stride));
         const fe x = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
-        u32* slot = reinterpret_cast<u32*>(out + 5 * (lo + j));
+        u32* slot = reinterpret_cast<u32*>(out + 5 * (lo + (size_t)j * stride));
 #pragma unroll
         for (int w = 0; w < 9; w++) slot[w] = acc.v[w];    // acc_{j-1} (R mod p for j = 0)
         acc = fp_mul(acc, x);
     }
-    // plain inverse of the register value: fp_invert returns acc^-1 * R^2
-    fe inv = mont_from<FP>(mont_from<FP>(fp_invert(acc)));
+    fe inv = fp_inverse_of_register(acc);                  // plain inverse of the register value
     for (int j = cnt - 1; j >= 0; j--) {
         u64 l[5], r[5];
-        load5(l, a + 5 * (lo + j));
+        load5(l, a + 5 * (lo + (size_t)j * stride));
         const bool z = limbs52_all_zero(l);
         const fe x = fe_select(z, neutral, fe_from_limbs52(l));
-        const u32* slot = reinterpret_cast<const u32*>(out + 5 * (lo + j));
+        const u32* slot = reinterpret_cast<const u32*>(out + 5 * (lo + (size_t)j * stride));
         fe pre;
 #pragma unroll
         for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
@@ -188,13 +396,13 @@ ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t
         inv = fp_mul(inv, x);
         if (num) {
             u64 ln[5];
-            load5(ln, num + 5 * (lo + j));
+            load5(ln, num + 5 * (lo + (size_t)j * stride));
             res = fp_mul(fe_from_limbs52(ln), mont_to<FP>(res));
         }
         fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(res)));
         if (z) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
-        store5(out + 5 * (lo + j), r);
-        if (ok) ok[lo + j] = z ? 0 : 1;
+        store5(out + 5 * (lo + (size_t)j * stride), r);
+        if (ok) ok[lo + (size_t)j * stride] = z ? 0 : 1;
     }
 }
 
@@ -816,32 +1024,33 @@ ZC_DI bool ed_to_affine(fe& x, fe& y, const pt& p)
     return !fp_is_zero(p.Z);
 }
 // One lane's share of a batched affine conversion: Montgomery's trick over the Z coordinates of
-// `c` consecutive points (as fe_invert_chunk: plain limbs are used as Montgomery residues, prefix
+// up to `c` points lo, lo + stride, ... (as fe_invert_chunk: plain limbs are used as Montgomery residues, prefix
 // products wait in the first 36 bytes of each 80-byte output record), then x = X/Z, y = Y/Z.
 // Z = 0 (the reference's inverse panics) takes the neutral value and yields (0, 0) / ok = 0.
-ZC_DI void ed_to_affine_chunk(const u64* p, u64* xy, uint8_t* ok, size_t n, size_t lo, int c)
+ZC_DI void ed_to_affine_chunk(const u64* p, u64* xy, uint8_t* ok, size_t n, size_t lo, size_t stride, int c)
 {
-    const int cnt = (int)((n - lo < (size_t)c) ? (n - lo) : (size_t)c);
+    const size_t avail = (n - lo + stride - 1) / stride;
+    const int cnt = (int)(avail < (size_t)c ? avail : (size_t)c);
     const fe neutral = fe_one_m<FP>();
     fe acc = neutral;
     for (int j = 0; j < cnt; j++) {
         u64 l[5];
-        load5(l, p + 20 * (lo + j) + 10);
+        load5(l, p + 20 * (lo + (size_t)j * stride) + 10);
         const fe z = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
-        u32* slot = reinterpret_cast<u32*>(xy + 10 * (lo + j));
+        u32* slot = reinterpret_cast<u32*>(xy + 10 * (lo + (size_t)j * stride));
 #pragma unroll
         for (int w = 0; w < 9; w++) slot[w] = acc.v[w];
         acc = fp_mul(acc, z);
     }
-    fe inv = mont_from<FP>(mont_from<FP>(fp_invert(acc)));
+    fe inv = fp_inverse_of_register(acc);
     for (int j = cnt - 1; j >= 0; j--) {
         u64 lx[5], ly[5], lz[5], r[5];
-        load5(lx, p + 20 * (lo + j));
-        load5(ly, p + 20 * (lo + j) + 5);
-        load5(lz, p + 20 * (lo + j) + 10);
+        load5(lx, p + 20 * (lo + (size_t)j * stride));
+        load5(ly, p + 20 * (lo + (size_t)j * stride) + 5);
+        load5(lz, p + 20 * (lo + (size_t)j * stride) + 10);
         const bool zero = limbs52_all_zero(lz);
         const fe z = fe_select(zero, neutral, fe_from_limbs52(lz));
-        const u32* slot = reinterpret_cast<const u32*>(xy + 10 * (lo + j));
+        const u32* slot = reinterpret_cast<const u32*>(xy + 10 * (lo + (size_t)j * stride));
         fe pre;
 #pragma unroll
         for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
@@ -849,11 +1058,11 @@ ZC_DI void ed_to_affine_chunk(const u64* p, u64* xy, uint8_t* ok, size_t n, size
         inv = fp_mul(inv, z);
         fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(fp_mul(fe_from_limbs52(lx), zinv))));
         if (zero) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
-        store5(xy + 10 * (lo + j), r);
+        store5(xy + 10 * (lo + (size_t)j * stride), r);
         fe_to_limbs52(r, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(fp_mul(fe_from_limbs52(ly), zinv))));
         if (zero) r[0] = r[1] = r[2] = r[3] = r[4] = 0;
-        store5(xy + 10 * (lo + j) + 5, r);
-        if (ok) ok[lo + j] = zero ? 0 : 1;
+        store5(xy + 10 * (lo + (size_t)j * stride) + 5, r);
+        if (ok) ok[lo + (size_t)j * stride] = zero ? 0 : 1;
     }
 }
 // Edwards equality = affine equality (edwards.rs:360-364, 1044-1048), cross-multiplied

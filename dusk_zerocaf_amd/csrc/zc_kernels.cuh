@@ -221,8 +221,8 @@ ZC_KERNEL void k_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
 // Zero elements (the reference panics) take the neutral value R mod p and yield 0 / ok = 0.
 ZC_KERNEL void k_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
 {
-    const size_t lo = gid() * (size_t)c;
-    if (lo < n) fe_invert_chunk(a, out, ok, n, lo, c);
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
+    if (g < lanes) fe_invert_chunk(a, out, ok, n, g, lanes, c);
 }
 ZC_KERNEL void k_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* was_square, size_t n)
 {
@@ -247,8 +247,8 @@ ZC_KERNEL void k_fe_div(const u64* a, const u64* b, u64* out, uint8_t* ok, size_
 }
 ZC_KERNEL void k_fe_div_chunked(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n, int c)
 {
-    const size_t lo = gid() * (size_t)c;
-    if (lo < n) fe_invert_chunk(b, out, ok, n, lo, c, a);
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
+    if (g < lanes) fe_invert_chunk(b, out, ok, n, g, lanes, c, a);
 }
 ZC_KERNEL void k_fe_half(const u64* a, u64* out, size_t n)                          // field.rs:317-323
 {
@@ -966,8 +966,8 @@ ZC_KERNEL void k_ed_to_affine(const u64* p, u64* xy, uint8_t* ok, size_t n)
 // large batches: one inversion per `c` consecutive points (ed_to_affine_chunk)
 ZC_KERNEL void k_ed_to_affine_chunked(const u64* p, u64* xy, uint8_t* ok, size_t n, int c)
 {
-    const size_t lo = gid() * (size_t)c;
-    if (lo < n) ed_to_affine_chunk(p, xy, ok, n, lo, c);
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
+    if (g < lanes) ed_to_affine_chunk(p, xy, ok, n, g, lanes, c);
 }
 ZC_KERNEL void k_ed_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 {

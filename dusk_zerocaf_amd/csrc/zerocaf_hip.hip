@@ -821,14 +821,26 @@ int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size
 int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
 int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40); }
 
+// Montgomery's trick shares one inversion among the c consecutive elements of a lane (3 multiplications per
+// element + one inversion per lane).  c = cnt / INV_LANES_TARGET keeps that many lanes busy, capped at 64;
+// below 2 the kernels take one element per lane.  ZC_INV_CHUNK=c overrides (tuning, tests).
+constexpr size_t INV_LANES_TARGET = 65536;
+inline size_t inv_chunk(size_t cnt)
+{
+    if (const char* e = getenv("ZC_INV_CHUNK")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 64) return (size_t)v;
+    }
+    size_t c = cnt / INV_LANES_TARGET;
+    return c > 32 ? 32 : c;
+}
+
 int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n)
 {
     REQUIRE(a); REQUIRE(out);
     Arg args[3] = {in_arg(a, 40), out_arg(out, 40), out_arg(ok, 1)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        // chunk length: keep >= 2 waves per SIMD busy (256 CUs x 4 SIMDs x 2 x 64 lanes), cap at 64
-        size_t c = cnt / 131072;
-        if (c > 64) c = 64;
+        const size_t c = inv_chunk(cnt);
         if (c < 2 || d[0] == d[1]) {                       // tiny batch or in-place: one element per lane
             hipLaunchKernelGGL(zc::k_fe_invert, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
         } else {
@@ -842,8 +854,7 @@ int zc_fe_div(zc_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, 
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     Arg args[4] = {in_arg(a, 40), in_arg(b, 40), out_arg(out, 40), out_arg(ok, 1)};
     return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
-        size_t c = cnt / 131072;                           // as zc_fe_invert
-        if (c > 64) c = 64;
+        const size_t c = inv_chunk(cnt);
         if (c < 2 || d[2] == d[0] || d[2] == d[1]) {
             hipLaunchKernelGGL(zc::k_fe_div, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
         } else {
@@ -991,8 +1002,7 @@ int zc_ed_to_affine(zc_ctx* ctx, const uint64_t* p, uint64_t* xy, uint8_t* ok, s
     REQUIRE(p); REQUIRE(xy);
     Arg args[3] = {in_arg(p, 160), out_arg(xy, 80), out_arg(ok, 1)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        size_t c = cnt / 131072;                           // as zc_fe_invert: >= 2 waves per SIMD stay busy
-        if (c > 64) c = 64;
+        const size_t c = inv_chunk(cnt);
         if (c < 2) {
             hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
         } else {

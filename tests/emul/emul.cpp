@@ -165,7 +165,8 @@ void emul_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 }
 extern "C" void emul_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
 {
-    for (size_t lo = 0; lo < n; lo += (size_t)c) fe_invert_chunk(a, out, ok, n, lo, c);
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c;      // as k_fe_invert_chunked: lane g takes g, g + lanes, ...
+    for (size_t g = 0; g < lanes; g++) fe_invert_chunk(a, out, ok, n, g, lanes, c);
 }
 // the MSM bucket accumulation's inner loop (zc_msm.cuh): cached-operand additions on the
 // independent-chain multiplier, through the packed 128-byte record
@@ -181,11 +182,13 @@ extern "C" void emul_bucket_sum(const u64* pts, size_t n, u64* out)
 }
 extern "C" void emul_ed_to_affine_chunked(const u64* pts, u64* xy, uint8_t* ok, size_t n, int c)
 {
-    for (size_t lo = 0; lo < n; lo += (size_t)c) ed_to_affine_chunk(pts, xy, ok, n, lo, c);
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c;
+    for (size_t g = 0; g < lanes; g++) ed_to_affine_chunk(pts, xy, ok, n, g, lanes, c);
 }
 extern "C" void emul_fe_div_chunked(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n, int c)
 {
-    for (size_t lo = 0; lo < n; lo += (size_t)c) fe_invert_chunk(b, out, ok, n, lo, c, a);
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c;
+    for (size_t g = 0; g < lanes; g++) fe_invert_chunk(b, out, ok, n, g, lanes, c, a);
 }
 extern "C" void emul_ed_scalar_mul_mode(const u64* p, const u64* k, u64* out, size_t n, int mode)
 {
