@@ -52,6 +52,7 @@ WORKLOADS = {
     # algorithmic bytes per unit: SURVEY 8(d)
     "scalar_mul": {"bytes": 360, "kernel": "k_ed_scalar_mul_pw (+ k_sm_cost_hist/scan/scatter)", "bound": "valu_int_mul", "unit": "scalar-muls/s"},
     "fe_mul": {"bytes": 120, "kernel": "k_fe_mul", "bound": "hbm", "unit": "field-muls/s"},
+    "fe_invert": {"bytes": 80, "kernel": "k_fe_invert_chunked", "bound": "hbm", "unit": "field-inversions/s"},
     "ristretto": {"bytes": 104, "kernel": "k_ris_roundtrip_mul_fast", "bound": "valu_int_mul", "unit": "round-trips/s"},
     "msm": {"bytes": 200, "kernel": "k_msm_runs (+ rocPRIM radix sort, k_msm_prepare/digits/runs_edges/segments/fold_groups/window_combine)",
             "bound": "valu_int_mul", "unit": "pairs/s"},
@@ -75,8 +76,10 @@ def make_inputs(eng, torch, n, seed, workload, scalar_bits=252):
 
     dev = torch.device("cuda", torch.cuda.current_device())
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
-    if workload == "fe_mul":
+    if workload in ("fe_mul", "fe_invert"):
         a, b = scalars(252), scalars(252)           # < 2^252 < p: canonical field elements
+        if workload == "fe_invert":
+            a[::1009] = 0                           # a few zeros: the reference's inverse() panics there (ok = 0, out = 0)
         return {"a": to_dev(a), "b": to_dev(b), "host": (a, b)}
     P = eng.ed_mul_base(to_dev(scalars(249)))
     torch.cuda.synchronize()
@@ -107,6 +110,8 @@ def cpu_baseline(workload, sample, data, n):
         for _ in range(reps):
             want = zc_ref.mt(zc_ref.fe_mul, a[:m], b[:m])
         m *= reps
+    elif workload == "fe_invert":
+        want = zc_ref.mt(zc_ref.fe_invert, data["host"][0][:m])
     elif workload == "scalar_mul":
         want = zc_ref.mt(zc_ref.ed_scalar_mul, host(data["P"]), data["host_K"][:m])
     elif workload == "ristretto":
@@ -190,6 +195,8 @@ def main():
         step = lambda: eng.ed_scalar_mul(data["P"], data["K"], out=out, flags=flags)
     elif wl == "fe_mul":
         step = lambda: eng.fe_mul(data["a"], data["b"])
+    elif wl == "fe_invert":
+        step = lambda: eng.fe_invert(data["a"])
     elif wl == "msm":
         # the whole exchange inside the library: local bucket method -> ncclAllGather of the 160-byte
         # partial sums on the library's own RCCL communicator -> ordered fold kernel -> host
@@ -324,11 +331,11 @@ def main():
     baseline_leg = world == 1 or sample > 0         # the CPU baseline is reported at N = 1 (or when asked for)
     if sample < 0:
         from oracle import zc_ref as _z
-        per_core = {"scalar_mul": 1 << 13, "ristretto": 1 << 12, "fe_mul": 1 << 24, "msm": 1 << 13}[wl]
-        sample = per_core * _z.host_threads() if world == 1 else {"fe_mul": 1 << 16}.get(wl, 1 << 11)   # N > 1: parity check only
+        per_core = {"scalar_mul": 1 << 13, "ristretto": 1 << 12, "fe_mul": 1 << 24, "fe_invert": 1 << 16, "msm": 1 << 13}[wl]
+        sample = per_core * _z.host_threads() if world == 1 else {"fe_mul": 1 << 16, "fe_invert": 1 << 14}.get(wl, 1 << 11)   # N > 1: parity check only
     if sample:
         v, cores, secs, total, want = cpu_baseline(wl, sample, data, n)
-        k = 0 if wl == "msm" else min(len(want[0] if wl == "ristretto" else want), n)
+        k = 0 if wl == "msm" else min(len(want[0] if wl in ("ristretto", "fe_invert") else want), n)
         if wl == "scalar_mul":
             torch.cuda.synchronize()
             got = out[:k].cpu().numpy().view(np.uint64)
@@ -341,6 +348,10 @@ def main():
             got = step()
             torch.cuda.synchronize()
             checked = bool(np.array_equal(got[:k].cpu().numpy().view(np.uint64), want))
+        elif wl == "fe_invert":
+            got, gok = step()
+            torch.cuda.synchronize()
+            checked = bool(np.array_equal(got[:k].cpu().numpy().view(np.uint64), want[0]) and np.array_equal(gok[:k].cpu().numpy(), want[1]))
         elif wl == "ristretto":
             torch.cuda.synchronize()
             wout, wok = want
@@ -355,7 +366,7 @@ def main():
                 checked = checked and bool(np.array_equal(zc_ref.ed_compress(msm_result[0])[0], zc_ref.ed_compress(want)[0]))
         if not checked:
             raise SystemExit("PARITY FAILURE: GPU result differs from the oracle")
-        what = {"scalar_mul": "zr_ed_scalar_mul (double_and_add)", "fe_mul": "zr_fe_mul", "ristretto": "zr_ris_roundtrip_mul (decompress, double_and_add, compress)",
+        what = {"scalar_mul": "zr_ed_scalar_mul (double_and_add)", "fe_mul": "zr_fe_mul", "fe_invert": "zr_fe_inverse (Savas-Koc, field.rs:854-925)", "ristretto": "zr_ris_roundtrip_mul (decompress, double_and_add, compress)",
                 "msm": "zr_msm_naive (sum of double_and_add results with the unified add)"}[wl]
         try:
             model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -371,7 +382,8 @@ def main():
                   "strict bit-exact mode" if args.mode == "strict" else "FAST non-strict mode"),
               "msm": "MSM point-scalar pairs/sec (bucket method per GPU, in-library RCCL all-gather + ordered fold across GPUs)",
               "ristretto": "Ristretto decompress -> scalar-mul -> compress round trips/sec (fused, bit-exact encodings)",
-              "fe_mul": "FieldElement multiplications/sec (batched, bit-exact canonical limbs)"}[wl]
+              "fe_mul": "FieldElement multiplications/sec (batched, bit-exact canonical limbs)",
+              "fe_invert": "FieldElement inversions/sec (batched, bit-exact canonical limbs)"}[wl]
     line = {
         "metric": metric, "value": round(value, 1), "unit": W["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -380,6 +392,7 @@ def main():
         "dtype": "u64 (nine 29-bit limbs in u32 registers, 64-bit multiply-accumulate columns)", "data": "synthetic",
         "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random %d-bit scalars (BASELINE configs[2])" % args.scalar_bits,
                                 "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
+                                "fe_invert": "2^20 FieldElement invert (BASELINE configs[1]); division-step inversion shared by up to 32 elements per lane",
                                 "ristretto": "Ristretto decompress->scalar-mul->compress, random %d-bit scalars, ~1%% undecodable inputs (BASELINE configs[3] shape)" % args.scalar_bits,
                                 "msm": "Pippenger MSM, %d-bit scalars, one shard per GPU (BASELINE configs[4] shape)" % args.scalar_bits}[wl],
                    "units_per_gpu_per_step": n,
@@ -388,6 +401,7 @@ def main():
                    "mode": {"scalar_mul": "strict (reference formula sequence, identical X:Y:Z:T limbs)" if args.mode == "strict"
                                           else "FAST (non-strict extra: same group element / encodings, limbs differ by a projective factor)",
                             "fe_mul": "bit-exact canonical limbs",
+                            "fe_invert": "bit-exact canonical limbs and ok mask (zero inputs)",
                             "ristretto": "bit-exact 32-byte encodings and ok mask",
                             "msm": "result compared as a group element (canonical encoding)"}[wl]},
         "roofline": roofline,

@@ -40,11 +40,12 @@ python bench.py --workload ristretto > "$OUT/bench_ristretto_2p20.json" 2>/dev/n
 python bench.py --workload ristretto --units 4194304 --steps 3 --warmup 1 > "$OUT/bench_ristretto_2p22.json" 2>/dev/null
 python bench.py --workload fe_mul > "$OUT/bench_fe_mul_2p20.json" 2>/dev/null
 python bench.py --workload fe_mul --units 16777216 --steps 20 --warmup 30 --cpu-sample 0 > "$OUT/bench_fe_mul_2p24.json" 2>/dev/null
+python bench.py --workload fe_invert > "$OUT/bench_fe_invert_2p20.json" 2>/dev/null
 python bench.py --workload msm > "$OUT/bench_msm_2p20.json" 2>/dev/null
 python bench.py --workload msm --units 2097152 > "$OUT/bench_msm_2p21.json" 2>/dev/null
 python bench.py --workload msm --units 16777216 --steps 3 --warmup 1 > "$OUT/bench_msm_2p24.json" 2>/dev/null
 python tools/bench_ops.py fe_add,fe_neg,fe_mul,fe_square 16777216 10 > "$OUT/ops.txt" 2>/dev/null
-python tools/bench_ops.py fe_invert,fe_sqrt_ratio_i,ed_add,ed_double,ed_compress,ed_decompress,ris_compress,ris_decompress,ed_to_affine 1048576 10 >> "$OUT/ops.txt" 2>/dev/null
+python tools/bench_ops.py fe_invert,fe_div,fe_sqrt_ratio_i,ed_add,ed_double,ed_compress,ed_decompress,ris_compress,ris_decompress,ed_to_affine 1048576 10 >> "$OUT/ops.txt" 2>/dev/null
 python tools/host_path.py 20 2>/dev/null | grep '"auto"\|"1"\|slots' > "$OUT/host_path.txt"
 python tools/host_path.py 22 2>/dev/null | grep '"auto"\|"1"\|slots' >> "$OUT/host_path.txt"
 ls -la "$OUT"
