@@ -51,7 +51,33 @@ assert np.array_equal(eng.sc_mul(sa, sb), par(zc_ref.sc_mul, m, sa, sb))
 inv, ok = eng.fe_invert(a[: 1 << 18])
 winv, wok = par(zc_ref.fe_invert, 1 << 18, a[: 1 << 18])
 assert np.array_equal(inv, winv) and np.array_equal(ok, wok)
+# batched division / affine conversion (strided Montgomery-trick chunks over the division-step inversion), ragged sizes
 rng = np.random.default_rng(seed)
+md = (1 << 18) + int(rng.integers(1, 1 << 17))
+q, qok = eng.fe_div(a[:md], b[:md]); wq, wqok = par(zc_ref.fe_div, md, a[:md], b[:md])
+assert np.array_equal(q, wq) and np.array_equal(qok, wqok), "fe_div"
+na = int(rng.integers(1 << 12, 1 << 16))
+xy, aok = eng.ed_to_affine(P[:na]); wxy, waok = par(zc_ref.ed_to_affine, na, P[:na])
+assert np.array_equal(xy, wxy) and np.array_equal(aok, waok), "ed_to_affine"
+# rows beside the default path: scalar recoders, Half / Pow / Shr, inv_sqrt, coset4, ProjectivePoint ops
+ms = 1 << 12
+assert np.array_equal(eng.sc_half(sa[:ms]), zc_ref.sc_half(sa[:ms]))
+assert np.array_equal(eng.sc_pow(sa[:256], sb[:256]), zc_ref.sc_pow(sa[:256], sb[:256]))
+rawk = V.rand_scalars_np(ms, seed * 100 + 40, bits=260)
+sh = int(rng.integers(0, 256))
+assert np.array_equal(eng.sc_shr(rawk, sh), zc_ref.sc_shr(rawk, sh))
+assert np.array_equal(eng.sc_into_bits(rawk), zc_ref.sc_into_bits(rawk))
+wdt = int(rng.choice([0, 2, 3, 4, 5, 6, 7]))
+both = np.concatenate([sa[:ms], rawk])
+assert np.array_equal(eng.sc_compute_naf(both, wdt), par(zc_ref.sc_compute_naf, len(both), both) if wdt == 0 else zc_ref.sc_compute_naf(both, wdt)), "naf width %d" % wdt
+isq, sq = eng.fe_inv_sqrt(a[:ms]); wisq, wsq = zc_ref.fe_inv_sqrt(a[:ms])
+assert np.array_equal(isq, wisq) and np.array_equal(sq, wsq)
+assert np.array_equal(eng.ed_coset4(P[:ms]), zc_ref.ed_coset4(P[:ms]))
+Pj, Qj = np.ascontiguousarray(P[:ms, :15]), np.ascontiguousarray(P[ms:2 * ms, :15])
+assert np.array_equal(eng.proj_sub(Pj, Qj), zc_ref.proj_sub(Pj, Qj)) and np.array_equal(eng.proj_neg(Pj), zc_ref.proj_neg(Pj))
+assert np.array_equal(eng.proj_scalar_mul(Pj[:512], rawk[:512]), par(zc_ref.proj_scalar_mul, 512, Pj[:512], rawk[:512])), "proj_scalar_mul"
+weq, wok2 = zc_ref.proj_eq(zc_ref.proj_add(Pj, Qj), zc_ref.proj_add(Qj, Pj))
+assert np.array_equal(eng.proj_eq(eng.proj_add(Pj, Qj), eng.proj_add(Qj, Pj)), weq & wok2) and weq.all()
 raw = rng.integers(0, 256, size=(1 << 15, 32), dtype=np.uint8); raw[:, 31] &= 0x1F
 d, ok = eng.ris_decompress(raw); wd, wok = par(zc_ref.ris_decompress, len(raw), raw)
 assert np.array_equal(d, wd) and np.array_equal(ok, wok)
