@@ -284,3 +284,73 @@ assert BASEPOINT[3] == BASEPOINT[0] * BASEPOINT[1] % P
 
 def pt_limbs(p):
     return [limbs(c) for c in p]
+
+
+# ------------------------------------------------------------------ rows beside the default path
+def sc_shr(k: int, s: int) -> int:
+    """Shr<u8> (backend scalar.rs:165-182): the limbs as one integer, shifted; no reduction."""
+    return k >> s
+
+
+def sc_into_bits(k: int):
+    """into_bits (backend scalar.rs:352-366): the 256 bits of to_bytes()."""
+    return [(k >> i) & 1 for i in range(256)]
+
+
+def sc_wnaf(k: int, width: int):
+    """compute_NAF (width 0, digits k mods 4) / compute_window_NAF(width) as the textbook integer
+    recoding: valid for 0 <= k < L - 2^width, where the reference's modular `k - Scalar::from(k_i)`
+    (backend scalar.rs:370-415) never wraps.  256 digits, least significant first."""
+    w = 2 if width == 0 else width
+    out = [0] * 256
+    i = 0
+    while k >= 1 and i < 256:
+        if k & 1:
+            d = k % (1 << w)
+            if d >= (1 << (w - 1)):
+                d -= 1 << w
+            out[i] = d
+            k -= d
+        k >>= 1
+        i += 1
+    return out
+
+
+def proj_add(p1, p2):
+    """ProjectivePoint add (edwards.rs:809-834), a = -1: BBJLP'08 add-2008-bbjlp on (X:Y:Z)."""
+    x1, y1, z1 = p1
+    x2, y2, z2 = p2
+    a = z1 * z2 % P
+    b = a * a % P
+    c = x1 * x2 % P
+    d = y1 * y2 % P
+    e = D * c % P * d % P
+    f = (b - e) % P
+    g = (b + e) % P
+    x3 = a * f % P * (((x1 + y1) * (x2 + y2) - c - d) % P) % P
+    y3 = a * g % P * ((d + c) % P) % P          # d - a*c with a = -1
+    return (x3, y3, f * g % P)
+
+
+def proj_double(p):
+    """ProjectivePoint double (edwards.rs:915-942): dbl-2008-bbjlp with a = -1."""
+    x, y, z = p
+    b = (x + y) * (x + y) % P
+    c = x * x % P
+    d = y * y % P
+    e = (-c) % P
+    f = (e + d) % P
+    h = z * z % P
+    j = (f - 2 * h) % P
+    return ((b - c - d) * j % P, f * ((e - d) % P) % P, f * j % P)
+
+
+def proj_scalar_mul(p, k: int):
+    """Mul<Scalar> for ProjectivePoint (edwards.rs:881-912) = double_and_add (:102-120), identity (0, 1, 1)."""
+    n, q = p, (0, 1, 1)
+    while k % (1 << 256) != 0:
+        if k & 1:
+            q = proj_add(q, n)
+        n = proj_double(n)
+        k >>= 1
+    return q

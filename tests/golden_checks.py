@@ -72,3 +72,23 @@ def check_backend(be, g):
     assert eq(be.ed_scalar_mul(rp, rkk), u64(rk["scalar_mul"]))
     out, ok = be.ris_roundtrip_mul(be.ris_compress(rp), rkk)
     assert ok.all() and eq(out, u8(rk["roundtrip_mul"]))
+    # rows beside the default path (SURVEY 8a S-x / F8 / E-x), same independent model
+    sr = g["sc_rows"]
+    a, e, raw = u64(sr["a"]), u64(sr["e"]), u64(sr["raw"])
+    assert eq(be.sc_half(a), u64(sr["half"])) and eq(be.sc_pow(a, e), u64(sr["pow"]))
+    for s, want in zip(sr["shifts"], sr["shr"]):
+        assert eq(be.sc_shr(raw, s), u64(want)), s
+    assert eq(be.sc_into_bits(raw), u8(sr["bits"]))
+    for w, want in zip(sr["naf_widths"], sr["naf"]):
+        assert eq(be.sc_compute_naf(u64(sr["naf_in"]), w), np.array(want, dtype=np.int8)), w
+    r, sq = be.fe_inv_sqrt(u64(fe["a"])[:96])
+    assert eq(sq, u8(fe["inv_sqrt_was_square"])) and eq(r, u64(fe["inv_sqrt"]))
+    er = g["ed_rows"]
+    assert eq(be.ed_coset4(p[:32]), u64(er["coset4"]))
+    pp, pq, pk = u64(er["proj_p"]), u64(er["proj_q"]), u64(er["proj_k"])
+    assert eq(be.proj_add(pp, pq), u64(er["proj_add"])) and eq(be.proj_double(pp), u64(er["proj_double"]))
+    assert eq(be.proj_neg(pp), u64(er["proj_neg"])) and eq(be.proj_sub(pp, pq), u64(er["proj_sub"]))
+    assert eq(be.proj_scalar_mul(pp, pk), u64(er["proj_scalar_mul"]))
+    assert eq(be.proj_is_valid(u64(er["proj_valid_in"])), u8(er["proj_valid"]))
+    pe = be.proj_eq(be.proj_add(pp, pq), be.proj_add(pq, pp))
+    assert np.asarray(pe[0] if isinstance(pe, tuple) else pe).all()
