@@ -853,24 +853,25 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
 // The reference's only fixed-base routine, window_naf_mul (edwards.rs:155-171), mis-indexes its
 // odd-multiples table and its test is commented out; the key-generation half of its ECDH bench
 // therefore uses the variable-base algorithms on BASEPOINT.  This is the correct fixed-base
-// counterpart: a comb table T[w][j] = (j+1) * 16^w * B (66 windows x 8 cached affine points, 66 KB,
-// L2-resident) and k*B = sum_w sign(d_w) * T[w][|d_w| - 1] over the signed radix-16 digits --
-// 66 cached additions, no doublings.  Equal to `&BASEPOINT * &k` as a group element; the fused
+// counterpart: a comb table T[w][j] = (j+1) * 256^w * B (33 windows x 128 cached affine points, 528 KB,
+// L2-resident) and k*B = sum_w sign(d_w) * T[w][|d_w| - 1] over the signed radix-256 digits --
+// 33 cached additions, no doublings (round 1 / first half of round 2: radix 16, 66 additions over a 66 KB table).  Equal to `&BASEPOINT * &k` as a group element; the fused
 // variant emits Ristretto encodings, which are bit-identical to the reference's.
-constexpr int ZC_BASE_WINDOWS = 66;
+constexpr int ZC_BASE_WINDOWS = 33;                      // signed radix-256 digits of a 260-bit scalar (+ carry)
+constexpr int ZC_BASE_ENTRIES = 128;                     // |digit| = 1 .. 128
 
-// lane j (0..7) builds the column (j+1) * 16^w * B for w = 0..65
+// lane j (0..127) builds the column (j+1) * 256^w * B for w = 0..32
 ZC_KERNEL void k_base_table_build(u32* table)
 {
     const int j = threadIdx.x;
-    if (j >= 8) return;
+    if (j >= ZC_BASE_ENTRIES) return;
     pt B;
     B.X = fe_const<FP>(ModP::BASE_X_M);
     B.Y = fe_const<FP>(ModP::BASE_Y_M);
     B.Z = fe_one_m<FP>();
     B.T = fe_const<FP>(ModP::BASE_T_M);
     pt P = B;
-    for (int a = 0; a < 7; a++) {
+    for (int a = 0; a < ZC_BASE_ENTRIES - 1; a++) {
         const pt s = pt_add(P, B);
         P = pt_select(a < j, s, P);                       // P = (j+1) * B
     }
@@ -882,12 +883,32 @@ ZC_KERNEL void k_base_table_build(u32* table)
         A.Y = fp_mul(P.Y, zi);
         A.Z = fe_one_m<FP>();
         A.T = fp_mul(A.X, A.Y);
-        niels_store(table + 32 * (w * 8 + j), niels_from_pt(A));
-        P = pt_add(P, P);
-        P = pt_add(P, P);
-        P = pt_add(P, P);
-        P = pt_add(P, P);
+        niels_store(table + 32 * (w * ZC_BASE_ENTRIES + j), niels_from_pt(A));
+#pragma unroll 1
+        for (int t = 0; t < 8; t++) P = pt_add(P, P);
     }
+}
+// Signed radix-256 digits of the 260-bit scalar, d_i in [-128, 128), 33 digits (carry included), stored as
+// bytes at dig[i * stride]; returns the index of the highest non-zero digit or -1.
+ZC_DI int scalar_digits256(int8_t* __restrict__ dig, int stride, const u64 (&l)[5])
+{
+    u32 w[9];
+    int nb;
+    {
+        u32 tmp[9];
+        scalar_to_words(tmp, 1, l, nb);
+#pragma unroll
+        for (int k = 0; k < 9; k++) w[k] = tmp[k];
+    }
+    int carry = 0, top = -1;
+    for (int i = 0; i < ZC_BASE_WINDOWS; i++) {
+        int d = (int)((w[i >> 2] >> ((i & 3) * 8)) & 255u) + carry;
+        carry = d >= 128;
+        d -= carry << 8;
+        dig[i * stride] = (int8_t)d;
+        if (d != 0) top = i;
+    }
+    return top;
 }
 ZC_DI pt base_mul(const u32* __restrict__ table, const int8_t* __restrict__ dig, int stride, int top)
 {
@@ -896,20 +917,20 @@ ZC_DI pt base_mul(const u32* __restrict__ table, const int8_t* __restrict__ dig,
         const int d = dig[w * stride];
         const int mag = d < 0 ? -d : d;
         niels c = niels_identity();
-        if (mag != 0) c = niels_load(table + 32 * (w * 8 + mag - 1));
+        if (mag != 0) c = niels_load(table + 32 * (w * ZC_BASE_ENTRIES + mag - 1));
         Q = pt_add_cached<false, true>(Q, niels_cond_neg(d < 0, c));     // table entries and the identity have z = 1
     }
     return Q;
 }
 ZC_KERNEL void k_ed_mul_base(const u64* k, u64* out, const u32* table, size_t n)
 {
-    __shared__ int8_t sdig[66 * ZC_BLOCK];
+    __shared__ int8_t sdig[ZC_BASE_WINDOWS * ZC_BLOCK];
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
     u64 l[5];
     load_scalar(l, k + 5 * (valid ? i : 0));
-    int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
+    int top = scalar_digits256(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
     top = wave_max_small(top);
     const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
@@ -918,13 +939,13 @@ ZC_KERNEL void k_ed_mul_base(const u64* k, u64* out, const u32* table, size_t n)
 // key generation: scalars -> compressed Ristretto public keys, (RISTRETTO_BASEPOINT * k).compress()
 ZC_KERNEL void k_ris_mul_base_compress(const u64* k, uint8_t* out, const u32* table, size_t n)
 {
-    __shared__ int8_t sdig[66 * ZC_BLOCK];
+    __shared__ int8_t sdig[ZC_BASE_WINDOWS * ZC_BLOCK];
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
     u64 l[5], w[4];
     load_scalar(l, k + 5 * (valid ? i : 0));
-    int top = scalar_digits16(sdig + tid, ZC_BLOCK, l);
+    int top = scalar_digits256(sdig + tid, ZC_BLOCK, l);
     if (!valid) top = -1;
     top = wave_max_small(top);
     const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
