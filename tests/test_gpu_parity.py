@@ -234,6 +234,34 @@ def test_fe_invert_bulk(eng, oracle):
     assert ok.all() and (prod[:, 0] == 1).all() and not prod[:, 1:].any()
 
 
+def test_batched_inversion_chunk_lengths(eng, oracle, monkeypatch):
+    """Montgomery's trick over strided chunks (lane g takes g, g + lanes, ...) around the division-step
+    inversion: every chunk length, ragged batch sizes that leave the last chunks short, zeros inside --
+    invert, Div and to_affine must not depend on the chunking and must equal the oracle."""
+    for n in (1, 63, 1000 + 7, 70001):
+        a = V.rand_fe_np(n, V.SEED + 180 + n)
+        num = V.rand_fe_np(n, V.SEED + 181 + n)
+        a[:: max(1, n // 7)] = 0
+        P = np.tile(V.base_multiples(oracle, min(n, 257), V.SEED + 182), (n // 257 + 1, 1))[:n].copy()
+        P[n // 2, 10:15] = 0                                       # Z = 0
+        m = min(n, 3000)
+        winv, wok = oracle.fe_invert(a[:m])
+        wq, wqok = oracle.fe_div(num[:m], a[:m])
+        wxy, waok = oracle.mt(oracle.ed_to_affine, P)
+        for c in ("1", "2", "3", "5", "16", "32", "64"):
+            monkeypatch.setenv("ZC_INV_CHUNK", c)
+            inv, ok = eng.fe_invert(a)
+            q, qok = eng.fe_div(num, a)
+            xy, aok = eng.ed_to_affine(P)
+            assert eq(inv[:m], winv) and eq(ok[:m], wok) and eq(q[:m], wq) and eq(qok[:m], wqok), (n, c)
+            assert eq(xy, wxy) and eq(aok, waok), (n, c)
+            if c == "1":
+                ref = (inv, ok, q, qok)
+            else:
+                assert all(eq(x, y) for x, y in zip(ref, (inv, ok, q, qok))), (n, c)
+    monkeypatch.delenv("ZC_INV_CHUNK")
+
+
 def test_fe_invert_chunked_exact(eng, oracle):
     """Batch sizes that take the Montgomery-trick kernel (chunks of 2 and 4 per lane) vs the
     oracle's Savas-Koc inverse, with zeros inside and at the ragged end."""
