@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device-resident fused Ristretto round trip (two-stream chunked launches) against the host-buffer
+"""Device-resident fused Ristretto round trip (one launch over the table ring) against the host-buffer
 path of the same library (2^18-element chunks, one stream) and the oracle on a sample."""
 import os, sys, json
 import numpy as np
