@@ -151,6 +151,26 @@ int main()
     }
     const auto rt = ristretto_roundtrip_mul_batch({Bp.compress(), hp.compress()}, {Y, X});
     CHECK(rt[0].has_value() && *rt[0] == (Bp * Y).compress() && rt[1].has_value() && *rt[1] == (hp * X).compress());
+    // ---- rows beside the default path through the mirror (scalar.rs tests :986-1050, edwards.rs:1450-1492, ristretto.rs:633-641)
+    {
+        const Scalar SA(L5{0, 0, 0, 2, 0});
+        const Scalar SB(L5{2766226127823335ull, 4237835465749098ull, 4503599626623787ull, 4503599627370493ull, 2199023255551ull});
+        CHECK(Y.half().l == L5{2320969958115016ull, 230956739268502ull, 2843239855579666ull, 3096217773921929ull, 871891328018ull});   // half (Y_HALF, scalar.rs:751)
+        CHECK((SA >> 1).l == L5{0, 0, 0, 1, 0} && (Scalar::one() >> 1).l == L5{0, 0, 0, 0, 0});               // shr
+        CHECK(SA.pow(SB).l == L5{2191545792217572ull, 448661815025744ull, 1377760471467833ull, 2830870192895755ull, 435342682203ull});   // pow (A_POW_B, scalar.rs:706)
+        CHECK(SA.pow(Scalar(2)).l == SA.square().l && SA.pow(Scalar(0)).l == Scalar::one().l);
+        const auto bits9 = Scalar(9).into_bits();
+        CHECK(bits9[0] == 1 && bits9[1] == 0 && bits9[2] == 0 && bits9[3] == 1 && bits9[4] == 0);           // into_bits
+        const auto naf7 = Scalar(7).compute_NAF();                                                           // scalar.rs:1024-1026
+        CHECK(naf7[0] == -1 && naf7[1] == 0 && naf7[2] == 0 && naf7[3] == 1 && naf7[4] == 0);
+        const auto w4 = Scalar(1122334455).compute_window_NAF(4);                                            // scalar.rs:1031-1050
+        CHECK(w4[0] == 7 && w4[4] == -1 && w4[8] == 7 && w4[12] == 7 && w4[16] == 5 && w4[30] == 1);
+        const ProjectivePoint q1{P1.X, P1.Y, P1.Z}, q2{P2.X, P2.Y, P2.Z};
+        CHECK((-ProjectivePoint::identity()) == ProjectivePoint::identity());                               // projective_coords_neg_identity
+        CHECK(q1 * Scalar(8) == q1.double_().double_().double_());                                         // projective_double_and_add
+        CHECK(q2.is_valid() && ((q1 + q2) - q2) == q1 && !(q1 == q2));
+        for (const EdwardsPoint& c : coset4(constants::BASEPOINT())) CHECK(RistrettoPoint{c} == Bp);         // four_coset_eq_basepoint
+    }
     Backend::synchronize();
     if (failures) { std::printf("%d FAILURES\n", failures); return 1; }
     std::printf("zerocaf.hpp: all reference-style checks passed\n");
