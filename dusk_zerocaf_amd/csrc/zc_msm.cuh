@@ -80,11 +80,25 @@ ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c,
 // so the bucket sums are free to use the cheaper dedicated a = -1 addition (HWCD'08 sec. 3.1,
 // 8 multiplications against a cached operand) instead of the reference's 10-multiplication
 // sequence; the sum is the same group element.
-ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
+ZC_KERNEL void k_msm_prepare_lane(const u64* points, u32* cached, size_t n)          // input array not 16-byte aligned
 {
     const size_t i = gid();
     if (i >= n) return;
     niels_store(cached + 32 * i, niels_from_pt(pt_load(points + 20 * i)));
+}
+// The pass is bandwidth-bound (160 bytes in, 128 out, five multiplications): the workgroup's 256 point
+// records (40 KB, contiguous) come in through LDS with coalesced 16-byte loads -- a lane reading its own
+// 160-byte record from global memory touches twenty 8-byte words on two or three cache lines it shares
+// with nobody in its wave -- and every lane writes one whole 128-byte line.
+ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) u64 sp[ZC_BLOCK * 20];
+    const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
+    const int cnt = (int)((n - base < (size_t)ZC_BLOCK) ? (n - base) : (size_t)ZC_BLOCK);
+    coop_load40<false>(sp, points + 20 * base, cnt * 4);         // a point = four 40-byte records
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < cnt) niels_store(cached + 32 * (base + t), niels_from_pt(pt_load(sp + 20 * t)));
 }
 // Bucket sums are kept in the kernels' own number system between k_msm_runs and k_msm_segments:
 // 36 x u32 (X, Y, Z, T as nine 29-bit Montgomery limbs each, R-class), 144 bytes per bucket.  A

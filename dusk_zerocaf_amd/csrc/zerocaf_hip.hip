@@ -564,7 +564,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         rocprim::double_buffer<zc::u32> kb(keys0, keys1), vb(vals0, vals1);
         size_t st = sort_tmp;
         HIP_TRY(rocprim::radix_sort_pairs(tmp, st, kb, vb, m, 0, (unsigned)keybits, D.s()));
-        hipLaunchKernelGGL(zc::k_msm_prepare, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
+        hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
         HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
         // bucket sums: segmented reduction of the sorted list in runs of T, level by level
         {
