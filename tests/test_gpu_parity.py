@@ -767,6 +767,34 @@ def test_fixed_base_key_generation(eng, oracle):
     assert ok1.all() and ok2.all() and eq(s12, s21)
 
 
+def test_fixed_base_comb_digit_edges(eng, oracle):
+    """The radix-256 comb recodes a scalar into signed digits in [-128, 128) with a carry that can run
+    through every window: byte patterns 0x80 / 0x7f / 0xff / 0x00 in every position and mix, raw limb
+    patterns up to 2^260 - 1 (the early-stopping loop rule applies to the reference product), small
+    and sparse scalars -- k*B as a point and (k*B).compress() must equal the reference's &BASEPOINT * &k."""
+    def from_bytes33(b):                                             # 33 little-endian bytes -> 5 x 52-bit limbs (260 bits)
+        v = int.from_bytes(bytes(b), "little") % (1 << 260)
+        return [(v >> (52 * j)) & ((1 << 52) - 1) for j in range(5)]
+    pats = []
+    for fill in (0x80, 0x7F, 0xFF, 0x00, 0x81, 0x01):
+        pats.append([fill] * 33)
+        for other in (0x80, 0x7F, 0xFF):
+            pats.append([fill if i % 2 else other for i in range(33)])
+            pats.append([other] * 5 + [fill] * 28)
+            pats.append([fill] * 31 + [other, 0x0F])
+    rng = np.random.default_rng(V.SEED + 190)
+    for _ in range(200):                                             # random mixes of the critical byte values
+        pats.append(rng.choice([0x00, 0x7F, 0x80, 0xFF, 0x01, 0x81], size=33).tolist())
+    K = np.array([from_bytes33(p) for p in pats], dtype=np.uint64)
+    K = np.concatenate([K, V.raw_scalar_edges(), np.array([[0] * 5, [1, 0, 0, 0, 0], [128, 0, 0, 0, 0], [127, 0, 0, 0, 0],
+                                                             [256, 0, 0, 0, 0], [(1 << 52) - 1] * 5], dtype=np.uint64)])
+    base = np.tile(np.array(sum(pm.pt_limbs(pm.BASEPOINT), []), dtype=np.uint64), (len(K), 1))
+    want = oracle.mt(oracle.ed_scalar_mul, base, K)
+    got = eng.ed_mul_base(K)
+    assert oracle.ed_eq(got, want).all()
+    assert eq(eng.ris_mul_base_compress(K), oracle.ris_compress(want))
+
+
 def test_msm_small(eng, oracle):
     for n in (1, 2, 3, 64, 257):                                  # scalar-mul + fold path
         P = V.base_multiples(oracle, n, V.SEED + 80 + n)
