@@ -474,6 +474,30 @@ ZC_DI pt pt_add(const pt& p, const pt& q)
     r.T = fp_mul(E, H);
     return r;
 }
+// The stand-alone point kernels (k_ed_add / sub / double / coset4) skip the Montgomery conversions: with PLAIN
+// canonical coordinates and the constant d in Montgomery form, every first-level product of pt_add comes out
+// with a factor 1/R (M, P, D directly; C = (dR * T1 / R) * T2 / R), the linear steps keep it, and the four
+// outputs carry 1/R^3 -- one multiplication by R^4 per coordinate returns the plain value.  13 multiplications
+// per addition instead of 8 (into the domain) + 9 + 4 (out of it); the canonical results are the same limbs.
+ZC_DI pt pt_load_plain(const u64* __restrict__ p)
+{
+    pt r;
+    u64 l[5];
+    load5(l, p);      r.X = fe_from_limbs52(l);
+    load5(l, p + 5);  r.Y = fe_from_limbs52(l);
+    load5(l, p + 10); r.Z = fe_from_limbs52(l);
+    load5(l, p + 15); r.T = fe_from_limbs52(l);
+    return r;
+}
+ZC_DI void pt_store_plain_r3(u64* __restrict__ o, const pt& p)           // p = (true value) / R^3 per coordinate
+{
+    const fe r4 = fe_const<FP>(ModP::R4);
+    u64 l[5];
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.X, r4)))); store5(o, l);
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.Y, r4)))); store5(o + 5, l);
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.Z, r4)))); store5(o + 10, l);
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.T, r4)))); store5(o + 15, l);
+}
 // The scalar-multiplication loop keeps its two points as (Y-X, Y+X, Z, T): the unified addition
 // consumes exactly these combinations of BOTH operands, so forming them once per result instead
 // of once per use saves a subtraction and an addition per step.  F and H skip the carry pass

@@ -474,21 +474,21 @@ ZC_KERNEL void k_ed_add(const u64* p, const u64* q, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_load(q + 20 * i)));
+    pt_store_plain_r3(out + 20 * i, pt_add(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)));   // plain domain: zc_curve.cuh
 }
 ZC_KERNEL void k_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
     // edwards.rs:503-531: add of the negated rhs with H = B - a*A == B + A (a = -1): same values
-    pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_neg(pt_load(q + 20 * i))));
+    pt_store_plain_r3(out + 20 * i, pt_add(pt_load_plain(p + 20 * i), pt_neg(pt_load_plain(q + 20 * i))));
 }
 ZC_KERNEL void k_ed_double(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    const pt a = pt_load(p + 20 * i);
-    pt_store(out + 20 * i, pt_add(a, a));
+    const pt a = pt_load_plain(p + 20 * i);
+    pt_store_plain_r3(out + 20 * i, pt_add(a, a));
 }
 ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
 {
@@ -1174,8 +1174,14 @@ ZC_KERNEL void k_ed_coset4(const u64* p, u64* out4, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    const pt P = pt_load(p + 20 * i);
-    pt_store(out4 + 80 * i, P);
+    const pt P = pt_load_plain(p + 20 * i);                 // plain domain (zc_curve.cuh: pt_load_plain)
+    {
+        u64 l[20];
+#pragma unroll
+        for (int q = 0; q < 20; q++) l[q] = p[20 * i + q];
+#pragma unroll
+        for (int q = 0; q < 20; q++) out4[80 * i + q] = l[q];
+    }
     for (int j = 0; j < 3; j++) {
         u64 x[5], y[5];
 #pragma unroll
@@ -1184,11 +1190,12 @@ ZC_KERNEL void k_ed_coset4(const u64* p, u64* out4, size_t n)
             y[q] = FOUR_COSET_XY[j][1][q];
         }
         pt C;
-        C.X = mont_to<FP>(fe_from_limbs52(x));
-        C.Y = mont_to<FP>(fe_from_limbs52(y));
-        C.Z = fe_one_m<FP>();
+        C.X = fe_from_limbs52(x);
+        C.Y = fe_from_limbs52(y);
+        C.Z = fe_zero();
+        C.Z.v[0] = 1;
         C.T = fe_zero();
-        pt_store(out4 + 80 * i + 20 * (j + 1), pt_add(P, C));
+        pt_store_plain_r3(out4 + 80 * i + 20 * (j + 1), pt_add(P, C));
     }
 }
 ZC_KERNEL void k_proj_neg(const u64* p, u64* out, size_t n)                          // edwards.rs:787-807: (-X, Y, Z)

@@ -93,6 +93,14 @@ void emul_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* sq, siz
 }
 void emul_ed_add(const u64* p, const u64* q, u64* out, size_t n)
 { for (size_t i = 0; i < n; i++) pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_load(q + 20 * i))); }
+// the stand-alone kernels' plain-domain path (k_ed_add / k_ed_sub / k_ed_double: no Montgomery conversions)
+void emul_ed_add_plain(const u64* p, const u64* q, u64* out, size_t n, int mode)
+{
+    for (size_t i = 0; i < n; i++) {
+        const pt a = pt_load_plain(p + 20 * i), b = pt_load_plain(q + 20 * i);
+        pt_store_plain_r3(out + 20 * i, mode == 0 ? pt_add(a, b) : mode == 1 ? pt_add(a, pt_neg(b)) : pt_add(a, a));
+    }
+}
 void emul_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
 { for (size_t i = 0; i < n; i++) pt_store(out + 20 * i, pt_add(pt_load(p + 20 * i), pt_neg(pt_load(q + 20 * i)))); }
 void emul_ed_scalar_mul(const u64* p, const u64* k, u64* out, size_t n)

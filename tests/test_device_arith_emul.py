@@ -103,6 +103,9 @@ def test_emul_point_ops(emul, oracle):
     assert np.array_equal(out, oracle.ed_add(P, Q))
     emul.emul_ed_sub(p(P), p(Q), p(out), C.c_size_t(n))
     assert np.array_equal(out, oracle.ed_sub(P, Q))
+    for mode, want in ((0, oracle.ed_add(P, Q)), (1, oracle.ed_sub(P, Q)), (2, oracle.ed_double(P))):   # plain-domain path
+        emul.emul_ed_add_plain(p(P), p(Q), p(out), C.c_size_t(n), mode)
+        assert np.array_equal(out, want), mode
     K = V.rand_scalars_np(n, V.SEED + 8, bits=252)
     K[0] = 0
     K[1] = [1, 0, 0, 0, 0]
