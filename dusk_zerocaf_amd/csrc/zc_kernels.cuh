@@ -494,7 +494,21 @@ ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    pt_store(out + 20 * i, pt_neg(pt_load(p + 20 * i)));
+    // Neg (edwards.rs:440-455): (-X, Y, Z, -T), the negations as the reference's own radix-2^52 borrow chain
+    // (field.rs:170-189 = 0 - a), Y and Z copied: no multiplication at all
+    u64 m[5], X[5], Y[5], Z[5], T[5], nx[5], nt[5];        // all loads first: `p` and `out` may alias for all the compiler knows
+    const u64 z[5] = {0, 0, 0, 0, 0};
+    limbs52_of_modulus<ModP>(m);
+    load5(X, p + 20 * i);
+    load5(Y, p + 20 * i + 5);
+    load5(Z, p + 20 * i + 10);
+    load5(T, p + 20 * i + 15);
+    sub52(nx, z, X, m);
+    sub52(nt, z, T, m);
+    store5(out + 20 * i, nx);
+    store5(out + 20 * i + 5, Y);
+    store5(out + 20 * i + 10, Z);
+    store5(out + 20 * i + 15, nt);
 }
 
 // ------------------------------------------------------------------ variable-base scalar multiplication
@@ -994,7 +1008,7 @@ ZC_KERNEL void k_ed_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    eq[i] = ed_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
+    eq[i] = ed_eq(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)) ? 1 : 0;   // cross products of plain coordinates: both sides carry 1/R
 }
 ZC_KERNEL_2W void k_ed_compress(const u64* p, uint8_t* out, uint8_t* ok, size_t n)
 {
@@ -1042,7 +1056,7 @@ ZC_KERNEL void k_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    eq[i] = ris_eq(pt_load(p + 20 * i), pt_load(q + 20 * i)) ? 1 : 0;
+    eq[i] = ris_eq(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)) ? 1 : 0;  // plain coordinates: both sides carry 1/R
 }
 // fused config-4 path: 32 B in -> registers -> 32 B out; the point never touches HBM
 ZC_KERNEL_2W void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, const u32* idx, size_t n)
@@ -1087,7 +1101,7 @@ ZC_KERNEL void k_ed_is_valid(const u64* p, uint8_t* valid, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    valid[i] = ed_is_valid(pt_load(p + 20 * i)) ? 1 : 0;
+    valid[i] = ed_is_valid(pt_load_plain(p + 20 * i)) ? 1 : 0;        // plain coordinates: both sides of the equation carry 1/R^3
 }
 // RistrettoPoint::is_valid (ristretto.rs:205-222): (P * L == identity) & on-curve
 ZC_KERNEL void k_ris_is_valid(const u64* p, uint8_t* valid, size_t n)
@@ -1202,9 +1216,16 @@ ZC_KERNEL void k_proj_neg(const u64* p, u64* out, size_t n)                     
 {
     const size_t i = gid();
     if (i >= n) return;
-    ppt a = ppt_load(p + 15 * i);
-    a.X = fe_reduce<FP>(fp_neg(a.X));
-    ppt_store(out + 15 * i, a);
+    u64 m[5], X[5], Y[5], Z[5], nx[5];                     // as k_ed_neg: radix-2^52 negation, Y and Z copied
+    const u64 z[5] = {0, 0, 0, 0, 0};
+    limbs52_of_modulus<ModP>(m);
+    load5(X, p + 15 * i);
+    load5(Y, p + 15 * i + 5);
+    load5(Z, p + 15 * i + 10);
+    sub52(nx, z, X, m);
+    store5(out + 15 * i, nx);
+    store5(out + 15 * i + 5, Y);
+    store5(out + 15 * i + 10, Z);
 }
 ZC_KERNEL void k_proj_sub(const u64* p, const u64* q, u64* out, size_t n)            // edwards.rs:851-879: self + (-other)
 {
@@ -1220,7 +1241,16 @@ ZC_KERNEL void k_proj_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    const ppt a = ppt_load(p + 15 * i), b = ppt_load(q + 15 * i);
+    ppt a, b;                                              // plain coordinates: both sides of each comparison carry 1/R
+    {
+        u64 l[5];
+        load5(l, p + 15 * i); a.X = fe_from_limbs52(l);
+        load5(l, p + 15 * i + 5); a.Y = fe_from_limbs52(l);
+        load5(l, p + 15 * i + 10); a.Z = fe_from_limbs52(l);
+        load5(l, q + 15 * i); b.X = fe_from_limbs52(l);
+        load5(l, q + 15 * i + 5); b.Y = fe_from_limbs52(l);
+        load5(l, q + 15 * i + 10); b.Z = fe_from_limbs52(l);
+    }
     const bool ex = fp_eq(fp_mul(a.X, b.Z), fp_mul(b.X, a.Z));
     const bool ey = fp_eq(fp_mul(a.Y, b.Z), fp_mul(b.Y, a.Z));
     eq[i] = (ex && ey && !fp_is_zero(a.Z) && !fp_is_zero(b.Z)) ? 1 : 0;
@@ -1229,9 +1259,12 @@ ZC_KERNEL void k_proj_is_valid(const u64* p, uint8_t* valid, size_t n)          
 {
     const size_t i = gid();
     if (i >= n) return;
-    const ppt a = ppt_load(p + 15 * i);
-    pt e;
-    e.X = a.X; e.Y = a.Y; e.Z = a.Z; e.T = fe_zero();
+    pt e;                                                  // plain coordinates, as k_ed_is_valid
+    u64 l[5];
+    load5(l, p + 15 * i); e.X = fe_from_limbs52(l);
+    load5(l, p + 15 * i + 5); e.Y = fe_from_limbs52(l);
+    load5(l, p + 15 * i + 10); e.Z = fe_from_limbs52(l);
+    e.T = fe_zero();
     valid[i] = ed_is_valid(e) ? 1 : 0;
 }
 // Mul<Scalar> for ProjectivePoint (edwards.rs:881-912) = double_and_add (:102-120) over the projective
