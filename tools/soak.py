@@ -59,6 +59,14 @@ assert np.array_equal(q, wq) and np.array_equal(qok, wqok), "fe_div"
 na = int(rng.integers(1 << 12, 1 << 16))
 xy, aok = eng.ed_to_affine(P[:na]); wxy, waok = par(zc_ref.ed_to_affine, na, P[:na])
 assert np.array_equal(xy, wxy) and np.array_equal(aok, waok), "ed_to_affine"
+# stand-alone point kernels (plain-domain formulas, multiplication-free negation, == / is_valid on plain coordinates)
+Qs = np.roll(P, 3, axis=0)
+assert np.array_equal(eng.ed_add(P, Qs), par(zc_ref.ed_add, n, P, Qs)) and np.array_equal(eng.ed_sub(P, Qs), par(zc_ref.ed_sub, n, P, Qs))
+assert np.array_equal(eng.ed_double(P), par(zc_ref.ed_double, n, P)) and np.array_equal(eng.ed_neg(P), zc_ref.ed_neg(P))
+mix = P.copy(); mix[::3] = Qs[::3]; mix[5, 10:15] = 0
+assert np.array_equal(eng.ed_eq(P, mix), (zc_ref.ed_eq(P, mix) == 1).astype(np.uint8)) and np.array_equal(eng.ris_eq(P, mix), zc_ref.ris_eq(P, mix))
+bad = P.copy(); bad[::4, 0] ^= np.uint64(1)
+assert np.array_equal(eng.ed_is_valid(bad), zc_ref.ed_is_valid(bad))
 # rows beside the default path: scalar recoders, Half / Pow / Shr, inv_sqrt, coset4, ProjectivePoint ops
 ms = 1 << 12
 assert np.array_equal(eng.sc_half(sa[:ms]), zc_ref.sc_half(sa[:ms]))
