@@ -47,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-MADS_PER_MUL = 135               # v_mad_u64_u32 per Montgomery multiplication (zc_arith.cuh, column-ordered)
+MADS_PER_MUL = 135               # v_mad_u64_u32 per Montgomery multiplication (zc_arith.hip.h, column-ordered)
 WORKLOADS = {
     # algorithmic bytes per unit: SURVEY 8(d)
     "scalar_mul": {"bytes": 360, "kernel": "k_ed_scalar_mul_pw (+ k_sm_cost_hist/scan/scatter)", "bound": "valu_int_mul", "unit": "scalar-muls/s"},

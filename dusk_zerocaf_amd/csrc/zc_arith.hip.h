@@ -1,4 +1,4 @@
-// zc_arith.cuh -- device-side modular arithmetic for the Sonny/Doppio field (mod p)
+// zc_arith.hip.h -- device-side modular arithmetic for the Sonny/Doppio field (mod p)
 // and the scalar field (mod L), one element per lane.
 //
 // Representation: nine 29-bit limbs in 32-bit VGPRs ("radix 2^29"), Montgomery
@@ -27,7 +27,7 @@
 // Column sums: 9 * 2^30 * 2^30 + 5 * 2^58 + 2^49 + carry < 2^63.4 < 2^64.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "zc_constants.cuh"
+#include "zc_constants.hip.h"
 
 namespace zc {
 

@@ -1,9 +1,9 @@
-// zc_curve.cuh -- device-side Edwards / Ristretto group law and codecs on top of
-// zc_arith.cuh.  One point per lane; coordinates live in VGPRs in Montgomery form
+// zc_curve.hip.h -- device-side Edwards / Ristretto group law and codecs on top of
+// zc_arith.hip.h.  One point per lane; coordinates live in VGPRs in Montgomery form
 // (R = 2^261, radix 2^29).  Every function cites the reference lines whose
 // *values* it reproduces (paths relative to the reference checkout).
 #pragma once
-#include "zc_arith.cuh"
+#include "zc_arith.hip.h"
 
 namespace zc {
 
@@ -364,7 +364,7 @@ ZC_DI bool limbs52_all_zero(const u64 (&l)[5]) { return (l[0] | l[1] | l[2] | l[
 ZC_DI fe fp_inverse_of_register(const fe& acc) { return fe_inverse_divsteps<FP>(fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(acc))); }
 
 // One lane's share of the batched inversion (Montgomery's trick over the up to `c` elements
-// lo, lo + stride, lo + 2 stride, ...; see k_fe_invert_chunked in zc_kernels.cuh: stride = number of
+// lo, lo + stride, lo + 2 stride, ...; see k_fe_invert_chunked in zc_kernels.hip.h: stride = number of
 // lanes, so that the lanes of a wave touch neighbouring records in every pass).
 // `num` != nullptr turns it into a batched division: out_j = num_j / a_j (Div, field.rs:277-300).
 ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, size_t stride, int c, const u64* num = nullptr)
@@ -912,7 +912,7 @@ ZC_DI int scalar_digits16(int8_t* __restrict__ dig, int stride, const u64 (&l)[5
 }
 
 // Where a lane's table lives.  table_ptr: a plain per-lane pointer (host emulation).  The kernels pass a
-// wave-uniform slot base instead (zc_kernels.cuh: ring_table) and form the lane's offset at every access, so
+// wave-uniform slot base instead (zc_kernels.hip.h: ring_table) and form the lane's offset at every access, so
 // that no per-lane pointer stays live in vector registers across the window loop.
 struct table_ptr {
     u32* p;

@@ -1,8 +1,8 @@
-// zc_kernels.cuh -- the __global__ kernels of libzerocaf_hip (gfx950).
+// zc_kernels.hip.h -- the __global__ kernels of libzerocaf_hip (gfx950).
 // Launch shape: 256-thread blocks (4 waves, one per SIMD), one element / point per
 // lane, grid = ceil(n / 256).  I/O arrays are the reference's own AoS limb layout.
 #pragma once
-#include "zc_curve.cuh"
+#include "zc_curve.hip.h"
 
 namespace zc {
 
@@ -474,7 +474,7 @@ ZC_KERNEL void k_ed_add(const u64* p, const u64* q, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    pt_store_plain_r3(out + 20 * i, pt_add(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)));   // plain domain: zc_curve.cuh
+    pt_store_plain_r3(out + 20 * i, pt_add(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)));   // plain domain: zc_curve.hip.h
 }
 ZC_KERNEL void k_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
 {
@@ -724,7 +724,7 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 }
 
 // ---- fast (non-strict) scalar multiplication ---------------------------------------------
-// scalar_mul_fast (zc_curve.cuh): fixed signed 4-bit windows, dedicated doubling, 8-mul cached
+// scalar_mul_fast (zc_curve.hip.h): fixed signed 4-bit windows, dedicated doubling, 8-mul cached
 // additions, per-lane table of 8 cached multiples in global scratch (1 KB per point, one cache
 // line per entry).  ~0.63x the multiplier work of the reference's formula sequence and no SIMT
 // divergence at all.  The result is the same group element as double_and_add's (identical
@@ -1188,7 +1188,7 @@ ZC_KERNEL void k_ed_coset4(const u64* p, u64* out4, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    const pt P = pt_load_plain(p + 20 * i);                 // plain domain (zc_curve.cuh: pt_load_plain)
+    const pt P = pt_load_plain(p + 20 * i);                 // plain domain (zc_curve.hip.h: pt_load_plain)
     {
         u64 l[20];
 #pragma unroll

@@ -1,4 +1,4 @@
-// zc_msm.cuh -- bucket-method (Pippenger) multi-scalar multiplication kernels.
+// zc_msm.hip.h -- bucket-method (Pippenger) multi-scalar multiplication kernels.
 // Not in the reference: sum_i k_i * P_i is specified through the reference's
 // own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU, one stream,
 // no host synchronisation anywhere:
@@ -29,8 +29,8 @@
 //      k_ed_fold_pairs down to one point per window
 //   7. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling
 #pragma once
-#include "zc_kernels.cuh"
-#include "zc_quad.cuh"
+#include "zc_kernels.hip.h"
+#include "zc_quad.hip.h"
 
 #ifndef ZC_MSM_ACC_ILP
 #define ZC_MSM_ACC_ILP false   // bucket sums on the column-ordered multiplier: with fixed-length runs every wave has

@@ -1,8 +1,8 @@
-// zc_quad.cuh -- one group-law evaluation shared by a quad of lanes (DPP quad broadcasts).
-// For work that is pure latency: the MSM window combination (zc_msm.cuh) and strict scalar
+// zc_quad.hip.h -- one group-law evaluation shared by a quad of lanes (DPP quad broadcasts).
+// For work that is pure latency: the MSM window combination (zc_msm.hip.h) and strict scalar
 // multiplications of batches so small that every SIMD holds a single wave anyway.
 #pragma once
-#include "zc_kernels.cuh"
+#include "zc_kernels.hip.h"
 
 namespace zc {
 
@@ -18,7 +18,7 @@ ZC_DI fe fe_by_role(int role, const fe& a, const fe& b, const fe& c, const fe& d
 {
     return fe_select(role < 2, fe_select(role == 0, a, b), fe_select(role == 2, c, d));
 }
-// The unified addition of the scalar-mul loop (ptm_add, zc_curve.cuh) on four lanes that all hold
+// The unified addition of the scalar-mul loop (ptm_add, zc_curve.hip.h) on four lanes that all hold
 // the same operands: phase 1 forms M, P, d*T1 and D on lanes 0..3, lane 2 finishes C = (d T1) T2,
 // phase 2 forms X3 = E F, Y3 = G H, Z3 = F G, T3 = E H.  Three multiplication latencies per step
 // instead of nine; every field value is the one ptm_add computes.

@@ -17,8 +17,8 @@
 #include <rccl/rccl.h>      // types only: librccl is opened with dlopen when a communicator is requested
 
 #include "../../include/zerocaf_hip.h"
-#include "zc_kernels.cuh"
-#include "zc_msm.cuh"
+#include "zc_kernels.hip.h"
+#include "zc_msm.hip.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -63,7 +63,7 @@ struct DevState {
     size_t bal_bytes = 0;
     void* msm = nullptr;                // bucket-method workspace (zc_msm)
     size_t msm_bytes = 0;
-    void* fast = nullptr;               // windowed-core tables: ring of wave slots, 256 MB (zc_kernels.cuh)
+    void* fast = nullptr;               // windowed-core tables: ring of wave slots, 256 MB (zc_kernels.hip.h)
     size_t fast_bytes = 0;
     void* ring = nullptr;               // tickets and slot flags of the table ring
     size_t ring_bytes = 0;
@@ -310,7 +310,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Streams larger than this (bytes over all arrays of the call) use the LDS-staged kernel
 // `k_stream` when one is given: it wins only for the compute-free two-input ops beyond the
-// 256 MB Infinity Cache (zc_kernels.cuh, "LDS-staged element I/O").
+// 256 MB Infinity Cache (zc_kernels.hip.h, "LDS-staged element I/O").
 constexpr size_t STREAM_BYTES = (size_t)256 << 20;
 
 int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
@@ -332,7 +332,7 @@ int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_
     });
 }
 
-// Cost-sorted permutation for the unified-step kernels (see zc_kernels.cuh "lane balancing").
+// Cost-sorted permutation for the unified-step kernels (see zc_kernels.hip.h "lane balancing").
 // Returns nullptr (natural order) for small batches or when scratch cannot be had.
 // ZC_BALANCE=global selects it; the default is the in-kernel block-local ranking, which keeps
 // HBM traffic algorithmic (a batch-wide permutation turns record reads into cache-line gathers).
@@ -378,7 +378,7 @@ inline strict_kernel_t strict_kernel_for(size_t cnt)
     return grid_for(cnt) <= SMALL_LAUNCH_BLOCKS ? zc::k_ed_scalar_mul_small : zc::k_ed_scalar_mul;
 }
 // The windowed-core kernels keep 1 KB of table scratch per lane in a ring of wave slots per XCD
-// (zc_kernels.cuh: ring_acquire / ring_release): 256 MB of tables plus 17 KB of tickets and flags, zeroed
+// (zc_kernels.hip.h: ring_acquire / ring_release): 256 MB of tables plus 17 KB of tickets and flags, zeroed
 // on the stream before every launch.  One launch covers the batch (the kernels index with 32 bits:
 // beyond 2^31 elements the batch goes in pieces, one after the other on the stream).
 // launch(table, ring_state, slots_per_xcd, offset, count).  ZC_RING_SLOTS=k (1..512) shrinks the ring so that
@@ -1208,7 +1208,7 @@ int zc_ris_mul_base_compress(zc_ctx* ctx, const uint64_t* k, uint8_t* out32, siz
 }
 
 // ---- MSM: sum_i k_i * P_i (not in the reference; specified as the reference's own
-// sum of `&P_i * &k_i`, src/edwards.rs:547-561 + :465-489).  Per GPU: bucket method (zc_msm.cuh)
+// sum of `&P_i * &k_i`, src/edwards.rs:547-561 + :465-489).  Per GPU: bucket method (zc_msm.hip.h)
 // for shards of >= MSM_BUCKET_MIN_N pairs, otherwise batched scalar-mul + pairwise folds.
 // The exchange step lives here: per-device partial sums are gathered INTO DEVICE MEMORY
 // (hipMemcpyPeerAsync inside one process, ncclAllGather between processes) and folded in

@@ -1,5 +1,5 @@
 // emul.cpp -- TEST-ONLY host build of the device arithmetic headers.
-// Compiles dusk_zerocaf_amd/csrc/zc_arith.cuh + zc_curve.cuh with g++ (the HIP
+// Compiles dusk_zerocaf_amd/csrc/zc_arith.hip.h + zc_curve.hip.h with g++ (the HIP
 // qualifiers expand to nothing under a non-HIP compiler) so the exact limb
 // algorithms the kernels run can be checked against the oracle in the CPU-only
 // test tier, before any GPU time is spent.  Never shipped, never loaded by
@@ -8,12 +8,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include "../../dusk_zerocaf_amd/csrc/zc_curve.cuh"
+#include "../../dusk_zerocaf_amd/csrc/zc_curve.hip.h"
 
-// -DZC_CHECK_BOUNDS build: every lazy-reduction precondition in zc_arith.cuh is asserted
+// -DZC_CHECK_BOUNDS build: every lazy-reduction precondition in zc_arith.hip.h is asserted
 extern "C" void zc_bound_fail(const char* what, int line)
 {
-    std::fprintf(stderr, "zc_arith.cuh:%d: bound violated: %s\n", line, what);
+    std::fprintf(stderr, "zc_arith.hip.h:%d: bound violated: %s\n", line, what);
     std::abort();
 }
 
@@ -176,7 +176,7 @@ extern "C" void emul_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size
     const size_t lanes = (n + (size_t)c - 1) / (size_t)c;      // as k_fe_invert_chunked: lane g takes g, g + lanes, ...
     for (size_t g = 0; g < lanes; g++) fe_invert_chunk(a, out, ok, n, g, lanes, c);
 }
-// the MSM bucket accumulation's inner loop (zc_msm.cuh): cached-operand additions on the
+// the MSM bucket accumulation's inner loop (zc_msm.hip.h): cached-operand additions on the
 // independent-chain multiplier, through the packed 128-byte record
 extern "C" void emul_bucket_sum(const u64* pts, size_t n, u64* out)
 {

@@ -25,7 +25,7 @@ def emul(request):
     so = os.path.join(EMUL_DIR, "libzc_emul_checked.so" if checked else "libzc_emul.so")
     src = os.path.join(EMUL_DIR, "emul.cpp")
     csrc = os.path.join(os.path.dirname(HERE), "dusk_zerocaf_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in ("zc_arith.cuh", "zc_curve.cuh", "zc_constants.cuh")]
+    deps = [src] + [os.path.join(csrc, f) for f in ("zc_arith.hip.h", "zc_curve.hip.h", "zc_constants.hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         inc = "/opt/rocm/include"
         if not os.path.isdir(inc):

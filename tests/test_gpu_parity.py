@@ -672,7 +672,7 @@ def test_ristretto_roundtrip_full_size_2_22(eng, oracle):
 
 def test_windowed_core_table_ring_under_contention(eng, oracle, monkeypatch):
     """The windowed core keeps its per-lane tables in a ring of wave slots per XCD (ring_acquire /
-    ring_release, zc_kernels.cuh).  With the default 512 slots per XCD a wave practically never waits
+    ring_release, zc_kernels.hip.h).  With the default 512 slots per XCD a wave practically never waits
     for a slot; ZC_RING_SLOTS shrinks the ring far below the number of resident waves, so that every
     slot is handed from wave to wave many times inside one launch.  Bytes, ok masks and points must
     not depend on the ring size, and must equal the oracle's."""

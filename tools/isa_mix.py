@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix of the unified-step loop of k_ed_scalar_mul, from the compiler's own ISA.
 
-Compiles the library source to gfx950 assembly (hipcc -S --cuda-device-only, no GPU needed), finds
+Compiles the library source to gfx950 assembly (hipcc -S --offload-device-only, no GPU needed), finds
 the largest backward-branch loop of the kernel and counts opcodes.  Writes the JSON named by --out (profiles/rNN_isa_mix.json),
 which tools/make_roofline_inputs.py uses to split the PMC instruction count into the multiplier-rate class
 (v_mad_u64_u32, v_mul_lo_u32, 64-bit shifts: ~5 cycles per wave-instruction per SIMD) and the rest.
@@ -23,7 +23,7 @@ SLOW = ("v_mad_u64_u32", "v_mad_i64_i32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lsh
 def compile_asm():
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "zc.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--offload-device-only",
                         "-o", asm, SRC], check=True, stderr=subprocess.DEVNULL)
         return open(asm).read()
 
@@ -57,7 +57,7 @@ def mix(text, kernel, whole=False, inner=False):
     ops = collections.Counter(l.split()[0] for l in lines[a:b] if not l.endswith(":"))
     valu = sum(v for k, v in ops.items() if k.startswith("v_"))
     slow = {k: v for k, v in ops.items() if k in SLOW}
-    return {"kernel": kernel, "source": "hipcc -S --cuda-device-only, " + ("whole kernel body" if whole else "largest inner loop"),
+    return {"kernel": kernel, "source": "hipcc -S --offload-device-only, " + ("whole kernel body" if whole else "largest inner loop"),
             "valu_per_step": valu, "multiplier_rate_class_per_step": sum(slow.values()), "multiplier_rate_class": slow,
             "multiplier_rate_share": round(sum(slow.values()) / valu, 4),
             "s_nop_per_step": ops.get("s_nop", 0),
