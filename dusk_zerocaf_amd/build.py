@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzerocaf_hip.so")
 SOURCES = ["zerocaf_hip.hip"]
-DEPS = ["zerocaf_hip.hip", "zc_kernels.hip.h", "zc_msm.hip.h", "zc_quad.hip.h", "zc_curve.hip.h", "zc_arith.hip.h", "zc_constants.hip.h",
+DEPS = ["zerocaf_hip.hip", "zc_kernels.hip.h", "zc_msm.hip.h", "zc_sort.hip.h", "zc_quad.hip.h", "zc_curve.hip.h", "zc_arith.hip.h", "zc_constants.hip.h",
         os.path.join("..", "..", "include", "zerocaf_hip.h")]
 
 

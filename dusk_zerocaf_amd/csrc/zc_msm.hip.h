@@ -3,14 +3,17 @@
 // own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU, one stream,
 // no host synchronisation anywhere:
 //   1. k_msm_digits   : SIGNED c-bit window digits d in (-2^(c-1), 2^(c-1)] of the effective scalar
-//                       (scalar_effective: double_and_add's termination rule) ->
-//                       (key = window << (c-1) | |d| - 1, value = point index | sign << 31);
-//                       zero digits get the sentinel key W << (c-1), which sorts behind every bucket.
+//                       (scalar_effective: double_and_add's termination rule), window-major:
+//                       keys[w n + i] = sign << 31 | (|d| - 1), or 2^(c-1) for a zero digit.
 //                       W = ceil(261 / c) windows hold any 260-bit pattern plus the last carry, so the
 //                       window count never depends on the data (empty windows cost empty buckets only).
-//   2. rocPRIM radix sort of the n*W pairs by key
-//   0. k_msm_prepare  : points -> cached form (Y-X, Y+X, Z, 2dT), Montgomery domain, packed to
-//                       one 128-byte cache line per point
+//   2. zc_sort.hip.h  : per-window LSD counting sort of the digit words -> pairs (global bucket =
+//                       window << (c-1) | |d| - 1, point index | sign << 31) ordered by bucket, zero
+//                       digits (key 0xFFFFFFFF) behind every bucket
+//   0. k_msm_prepare  : points -> cached form, Montgomery domain.  Large batches: AFFINE records
+//                       (y-x, y+x, 2dxy), 96 bytes, one division-step inversion per lane shared by its
+//                       points (Montgomery's trick), so that a bucket addition costs 7 multiplications;
+//                       small batches: (Y-X, Y+X, Z, 2dT), one 128-byte cache line, 8 multiplications
 //   3. k_msm_runs     : the bucket sums as a SEGMENTED REDUCTION of the sorted list in fixed-length
 //                       runs: lane j adds the T consecutive entries [jT, (j+1)T) whatever buckets they
 //                       belong to, so every lane does the same work however skewed the digit
@@ -31,6 +34,7 @@
 #pragma once
 #include "zc_kernels.hip.h"
 #include "zc_quad.hip.h"
+#include "zc_sort.hip.h"
 
 #ifndef ZC_MSM_ACC_ILP
 #define ZC_MSM_ACC_ILP false   // bucket sums on the column-ordered multiplier: with fixed-length runs every wave has
@@ -58,20 +62,19 @@ ZC_DI u32 scalar_bits(const u64 (&l)[5], int bit, int c)
     return (u32)x & (u32)(((u64)1 << c) - 1);
 }
 
-ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, u32* vals, size_t n, int c, int W)
+ZC_KERNEL void k_msm_digits(const u64* k, u32* keys, size_t n, int c, int W)
 {
     const size_t i = gid();
     if (i >= n) return;
     u64 l[5];
     load_scalar(l, k + 5 * i);
-    const u32 half = 1u << (c - 1), sentinel = (u32)W << (c - 1);
+    const u32 half = 1u << (c - 1);
     u32 carry = 0;
     for (int w = 0; w < W; w++) {
         const u32 raw = scalar_bits(l, w * c, c) + carry;              // 0 .. 2^c
         carry = raw > half ? 1u : 0u;                                    // digit = raw - carry * 2^c
         const u32 mag = carry ? (1u << c) - raw : raw;                   // |digit| in 0 .. 2^(c-1)
-        keys[(size_t)w * n + i] = mag ? (((u32)w << (c - 1)) | (mag - 1)) : sentinel;
-        vals[(size_t)w * n + i] = (u32)i | (carry << 31);
+        keys[(size_t)w * n + i] = (mag ? mag - 1 : half) | (carry << 31);
     }
 }
 
@@ -99,6 +102,69 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
     __syncthreads();
     const int t = threadIdx.x;
     if (t < cnt) niels_store(cached + 32 * (base + t), niels_from_pt(pt_load(sp + 20 * t)));
+}
+// AFFINE records (large batches): (y - x, y + x, 2 d x y) as 3 x 256-bit words = 96 bytes, Montgomery domain; the
+// bucket additions then skip Z Z' (pt_add_cached<., AFFINE>: 7 multiplications instead of 8) and gather 96
+// bytes instead of 128.  One lane normalises the points lo, lo + stride, ... (at most c; stride = number of
+// lanes, so a wave touches neighbouring records in every pass) with ONE division-step inversion: Montgomery's
+// trick over their Z coordinates, the prefix products parked in the first 36 bytes of the records about to be
+// written (as ed_to_affine_chunk: plain limbs serve as Montgomery residues, fp_inverse_of_register returns the
+// plain inverse of the register value).  A wave whose points all have Z = 1 (decompressed or already affine
+// inputs) skips the inversion.  Z = 0 (no point of the curve) takes the neutral value: garbage in, garbage out.
+constexpr int MSM_AFF_WORDS = 24;
+ZC_DI void msm_prepare_affine_chunk(const u64* __restrict__ p, u32* __restrict__ recs, size_t n, size_t lo, size_t stride, int c)
+{
+    const size_t avail = lo < n ? (n - lo + stride - 1) / stride : 0;
+    const int cnt = (int)(avail < (size_t)c ? avail : (size_t)c);
+    const fe neutral = fe_one_m<FP>();
+    fe acc = neutral;
+    bool all_one = true;
+    for (int j = 0; j < cnt; j++) {
+        const size_t i = lo + (size_t)j * stride;
+        u64 l[5];
+        load5(l, p + 20 * i + 10);
+        all_one = all_one && l[0] == 1 && (l[1] | l[2] | l[3] | l[4]) == 0;
+        const fe z = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
+        u32* slot = recs + MSM_AFF_WORDS * i;
+#pragma unroll
+        for (int w = 0; w < 9; w++) slot[w] = acc.v[w];
+        acc = fp_mul(acc, z);
+    }
+    const bool skip = __all(all_one) != 0;                  // wave-uniform
+    fe inv = neutral;
+    if (!skip) inv = fp_inverse_of_register(acc);
+    const fe d2 = fe_const<FP>(ModP::D2_M);
+    for (int j = cnt - 1; j >= 0; j--) {
+        const size_t i = lo + (size_t)j * stride;
+        u64 lx[5], ly[5], lz[5], lt[5];
+        load5(lx, p + 20 * i);
+        load5(ly, p + 20 * i + 5);
+        load5(lz, p + 20 * i + 10);
+        load5(lt, p + 20 * i + 15);
+        u32* slot = recs + MSM_AFF_WORDS * i;
+        fe zi2 = fe_const<FP>(ModP::RR);                        // (1 / Z) R^2
+        if (!skip) {
+            const fe z = fe_select(limbs52_all_zero(lz), neutral, fe_from_limbs52(lz));
+            fe pre;
+#pragma unroll
+            for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
+            zi2 = fp_mul(fp_mul(inv, pre), fe_const<FP>(ModP::R3));
+            inv = fp_mul(inv, z);
+        }
+        const fe xm = fp_mul(fe_from_limbs52(lx), zi2);         // x R
+        const fe ym = fp_mul(fe_from_limbs52(ly), zi2);         // y R
+        const fe tm = fp_mul(fe_from_limbs52(lt), zi2);         // (T / Z) R = x y R
+        fe ypx = fe_add(ym, xm);
+        fe_carry(ypx);
+        pack256(slot, fp_sub(ym, xm));                          // normalized, < 7N < 2^256
+        pack256(slot + 8, ypx);
+        pack256(slot + 16, fp_mul(tm, d2));
+    }
+}
+ZC_KERNEL void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c)
+{
+    const size_t lanes = ((n + (size_t)c - 1) / (size_t)c + 63) & ~(size_t)63, g = gid();      // whole waves: the skip vote is wave-wide
+    if (g < lanes) msm_prepare_affine_chunk(points, recs, n, g, lanes, c);
 }
 // Bucket sums are kept in the kernels' own number system between k_msm_runs and k_msm_segments:
 // 36 x u32 (X, Y, Z, T as nine 29-bit Montgomery limbs each, R-class), 144 bytes per bucket.  A
@@ -189,13 +255,14 @@ ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 
 #define ZC_MSM_RUN_BLOCK 256   // threads per workgroup of k_msm_runs (its waves never synchronise: A/B knob)
 #endif
 constexpr int MSM_RUN_BLOCK = ZC_MSM_RUN_BLOCK;
-extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
-void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+template <bool AFFINE>
+ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict__ recs, u32 len, u32 T, u32 nbuckets,
+                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
 {
-    __shared__ uint4 stage[8 * MSM_RUN_BLOCK];
+    constexpr int PIECES = AFFINE ? 6 : 8;                     // 16-byte pieces of a cached record
+    __shared__ uint4 stage[PIECES * MSM_RUN_BLOCK];
     const int lane = threadIdx.x & 63;
-    uint4* base = stage + (threadIdx.x >> 6) * (8 * 64);
+    uint4* base = stage + (threadIdx.x >> 6) * (PIECES * 64);
     const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
     const u64 lo64 = (u64)j * T;
     if (lo64 >= len) return;
@@ -204,40 +271,46 @@ void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T
     const u32 none = 0xFFFFFFFFu;
     next_keys[2 * (size_t)j] = none;                           // this lane's two edge slots: unused until msm_flush says otherwise
     next_keys[2 * (size_t)j + 1] = none;
-    u32 cur_key = keys[lo];
+    const uint2 cur = pairs[lo];
+    u32 cur_key = cur.x;
     if (cur_key >= nbuckets) return;                           // zero digits sort behind every bucket: nothing to add
-    const u32 prev_key = lo > 0 ? keys[lo - 1] : none;
-    const u32 next_key = hi < len ? keys[hi] : none;
+    const u32 prev_key = lo > 0 ? pairs[lo - 1].x : none;
+    const u32 next_key = hi < len ? pairs[hi].x : none;
     auto fetch = [&](u32 v) {
 #ifdef ZC_MSM_PROBE_NOGATHER   // timing probe only (wrong sums): every gather hits one of 256 cache-resident records
-        const uint4* src = reinterpret_cast<const uint4*>(recs + 32 * (size_t)(v & 0xFFu));
+        const uint4* src = reinterpret_cast<const uint4*>(recs + 4 * PIECES * (size_t)(v & 0xFFu));
 #else
-        const uint4* src = reinterpret_cast<const uint4*>(recs + 32 * (size_t)(v & 0x7FFFFFFFu));
+        const uint4* src = reinterpret_cast<const uint4*>(recs + 4 * PIECES * (size_t)(v & 0x7FFFFFFFu));
 #endif
 #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < PIECES; q++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q),
                                              (__attribute__((address_space(3))) void*)(base + q * 64), 16, 0, 0);
     };
     pt acc = pt_identity();
-    u32 vcur = idx[lo];
+    u32 vcur = cur.y;
     fetch(vcur);
-    u32 vnext = (lo + 1 < hi) ? idx[lo + 1] : 0;
-    u32 knext = (lo + 1 < hi) ? keys[lo + 1] : none;
+    uint2 nxt = (lo + 1 < hi) ? pairs[lo + 1] : make_uint2(none, 0);
     bool first = true;
     for (u32 e = lo; e < hi; e++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        niels cur;
-        cur.ymx = unpack256(base[0 * 64 + lane], base[1 * 64 + lane]);
-        cur.ypx = unpack256(base[2 * 64 + lane], base[3 * 64 + lane]);
-        cur.z = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
-        cur.t2d = unpack256(base[6 * 64 + lane], base[7 * 64 + lane]);
+        niels q;
+        q.ymx = unpack256(base[0 * 64 + lane], base[1 * 64 + lane]);
+        q.ypx = unpack256(base[2 * 64 + lane], base[3 * 64 + lane]);
+        if (AFFINE) {
+            q.z = fe_zero();                                   // unused: Z' = 1
+            q.t2d = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
+        } else {
+            q.z = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
+            q.t2d = unpack256(base[(PIECES - 2) * 64 + lane], base[(PIECES - 1) * 64 + lane]);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool neg = (vcur >> 31) != 0;
-        if (e + 1 < hi) fetch(vnext);
-        vcur = vnext;
-        vnext = (e + 2 < hi) ? idx[e + 2] : 0;
-        acc = pt_add_cached<ZC_MSM_ACC_ILP>(acc, niels_cond_neg(neg, cur));
+        const u32 knext = nxt.x;
+        if (e + 1 < hi) fetch(nxt.y);
+        vcur = nxt.y;
+        nxt = (e + 2 < hi) ? pairs[e + 2] : make_uint2(none, 0);
+        acc = pt_add_cached<ZC_MSM_ACC_ILP, AFFINE>(acc, niels_cond_neg(neg, q));
         const bool last = e + 1 == hi;
         if (last || knext != cur_key) {                        // the segment ends with this entry
             msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
@@ -246,8 +319,19 @@ void k_msm_runs(const u32* keys, const u32* idx, const u32* recs, u32 len, u32 T
             cur_key = knext;
             if (cur_key >= nbuckets) break;                    // only zero digits follow
         }
-        knext = (e + 2 < hi) ? keys[e + 2] : none;
     }
+}
+extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
+void k_msm_runs(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+{
+    msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs);
+}
+extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
+void k_msm_runs_affine(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+{
+    msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs);
 }
 
 // Levels >= 1: the edge list of the level above (raw 144-byte records in list order, sentinel keys in

@@ -20,8 +20,6 @@
 #include "zc_kernels.hip.h"
 #include "zc_msm.hip.h"
 
-#include <rocprim/rocprim.hpp>
-
 using zc::u64;
 
 namespace {
@@ -487,6 +485,79 @@ int msm_window_bits(size_t cnt)
     return c;
 }
 
+// The key sort of the MSM (zc_sort.hip.h): `passes` stable counting-sort passes over the c - 1 digit bits of
+// every window, at most 9 bits each.  A table column = G tiles of 4096 keys walked by one workgroup of the
+// scatter kernel; G grows with the batch so that every window keeps about 128 columns (2^21 pairs per window:
+// G = 4; 2^24: G = 16), which bounds the table (windows x bins x columns words) at a few MB.
+struct MsmSortPlan {
+    int passes = 0;
+    zc::msm_sort_pass pass[4];
+    size_t table_words = 0;                                   // largest table, padded to whole scan blocks
+};
+MsmSortPlan msm_sort_plan(size_t n, int c, int W)
+{
+    MsmSortPlan pl;
+    const int B = c - 1;
+    pl.passes = (B + zc::MSM_SORT_PASS_BITS - 1) / zc::MSM_SORT_PASS_BITS;
+    const size_t ntiles = (n + zc::MSM_SORT_TILE - 1) / zc::MSM_SORT_TILE;
+    size_t G = ntiles / 128;
+    G = std::max<size_t>(1, std::min<size_t>(16, G));
+    if (const char* e = getenv("ZC_MSM_SORT_G")) {
+        const long f = atol(e);
+        if (f >= 1 && f <= 64) G = (size_t)f;
+    }
+    const size_t ncols = (ntiles + G - 1) / G;
+    int shift = 0;
+    for (int i = 0; i < pl.passes; i++) {
+        const int bits = B / pl.passes + (i < B % pl.passes ? 1 : 0);
+        zc::msm_sort_pass& p = pl.pass[i];
+        p.n = (zc::u32)n;
+        p.W = (zc::u32)W;
+        p.G = (zc::u32)G;
+        p.ncols = (zc::u32)ncols;
+        p.shift = (zc::u32)shift;
+        p.bits = (zc::u32)bits;
+        p.last = i + 1 == pl.passes ? 1u : 0u;
+        p.c = (zc::u32)c;
+        shift += bits;
+        const size_t words = ((size_t)W * ((size_t)1 << bits) + (p.last ? (size_t)W : 0)) * ncols;
+        pl.table_words = std::max(pl.table_words, (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS);
+    }
+    return pl;
+}
+// digits (window-major words in `digits`) -> pairs ordered by bucket; returns the buffer that holds them
+int msm_sort(DevState& D, const MsmSortPlan& pl, const zc::u32* digits, uint2* buf_a, uint2* buf_b, zc::u32* table, zc::u32* sums, const uint2** sorted)
+{
+    const zc::u32* in = digits;
+    uint2* out = buf_a;
+    for (int i = 0; i < pl.passes; i++) {
+        const zc::msm_sort_pass& p = pl.pass[i];
+        const size_t words = ((size_t)p.W * ((size_t)1 << p.bits) + (p.last ? (size_t)p.W : 0)) * p.ncols;
+        const size_t padded = (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS;
+        const unsigned nblk = (unsigned)(padded / zc::SCAN_BLOCK_ELEMS), grid = (unsigned)(p.W * p.ncols);
+        if (padded > words) HIP_TRY(hipMemsetAsync(table + words, 0, (padded - words) * sizeof(zc::u32), D.s()));
+        hipLaunchKernelGGL(i ? zc::k_msm_sort_hist_pairs : zc::k_msm_sort_hist, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, table, p);
+        hipLaunchKernelGGL(zc::k_scan_reduce, dim3(nblk), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)table, sums);
+        hipLaunchKernelGGL(zc::k_scan_sums, dim3(1), dim3(zc::ZC_BLOCK), 0, D.s(), sums, (zc::u32)nblk);
+        hipLaunchKernelGGL(zc::k_scan_apply, dim3(nblk), dim3(zc::ZC_BLOCK), 0, D.s(), table, (const zc::u32*)sums);
+        hipLaunchKernelGGL(i ? zc::k_msm_sort_scatter_pairs : zc::k_msm_sort_scatter, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, out, (const zc::u32*)table, p);
+        in = reinterpret_cast<const zc::u32*>(out);
+        *sorted = out;
+        out = out == buf_a ? buf_b : buf_a;
+    }
+    return ZC_OK;
+}
+
+// Affine cached records (7-multiplication bucket additions, 96-byte gathers) from this many points on: the
+// normalisation costs one division-step inversion per lane, which small batches cannot amortise.
+// ZC_MSM_AFFINE=0/1 forces the choice (tests, A/B).
+constexpr size_t MSM_AFFINE_MIN_N = (size_t)1 << 17;
+inline bool msm_affine(size_t cnt)
+{
+    if (const char* e = getenv("ZC_MSM_AFFINE")) return atoi(e) != 0;
+    return cnt >= MSM_AFFINE_MIN_N;
+}
+
 // sum_i k_i P_i of one device's shard, enqueued on D.s() without any host synchronisation;
 // *result points at the 160-byte sum in D's memory (valid until the next MSM on this device).
 int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u64** result)
@@ -519,8 +590,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     const size_t nb = (size_t)W << (c - 1);               // buckets (digit magnitudes 1 .. 2^(c-1) per window)
     const int seg = zc::msm_segment_buckets(nb);
     const size_t nseg = nb / (size_t)seg;
-    int keybits = c - 1;
-    while (((size_t)1 << keybits) <= nb) keybits++;       // the sentinel key nb must sort last
+    const MsmSortPlan plan = msm_sort_plan(cnt, c, W);
+    const bool affine = msm_affine(cnt);
 
     // run length of the segmented reduction: 128 entries per lane, fewer when the list is short (keep
     // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
@@ -537,18 +608,13 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         if (f >= 4 && f <= 4096) TE = f & ~1;
     }
     const size_t nl0 = (m + T - 1) / T;                   // lanes (= runs) of level 0
-    size_t sort_tmp = 0;
-    {
-        rocprim::double_buffer<zc::u32> kq(nullptr, nullptr), vq(nullptr, nullptr);
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tmp, kq, vq, m, 0, (unsigned)keybits, D.s()));
-    }
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
-        zc::u32* keys0 = cv.take<zc::u32>(m);
-        zc::u32* keys1 = cv.take<zc::u32>(m);
-        zc::u32* vals0 = cv.take<zc::u32>(m);
-        zc::u32* vals1 = cv.take<zc::u32>(m);
-        char* tmp = cv.take<char>(sort_tmp);
+        zc::u32* digits = cv.take<zc::u32>(m);
+        uint2* pairs_a = cv.take<uint2>(m);
+        uint2* pairs_b = plan.passes > 1 ? cv.take<uint2>(m) : nullptr;
+        zc::u32* sort_table = cv.take<zc::u32>(plan.table_words);
+        zc::u32* sort_sums = cv.take<zc::u32>(plan.table_words / zc::SCAN_BLOCK_ELEMS + 1);
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
         uint8_t* present = cv.take<uint8_t>(nb);
@@ -563,15 +629,29 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             if (rc) return rc;
             continue;
         }
-        hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, keys0, vals0, cnt, c, W);
-        rocprim::double_buffer<zc::u32> kb(keys0, keys1), vb(vals0, vals1);
-        size_t st = sort_tmp;
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, st, kb, vb, m, 0, (unsigned)keybits, D.s()));
-        hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
+        hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, digits, cnt, c, W);
+        const uint2* sorted = nullptr;
+        {
+            int rc = msm_sort(D, plan, digits, pairs_a, pairs_b, sort_table, sort_sums, &sorted);
+            if (rc) return rc;
+        }
+        if (affine) {
+            // points per lane of the normalisation: enough lanes for two to four waves per SIMD, enough points per
+            // lane to amortise its inversion (ZC_MSM_AFFINE_CHUNK overrides)
+            int ac = (int)std::min<size_t>(16, std::max<size_t>(1, cnt >> 18));
+            if (const char* e = getenv("ZC_MSM_AFFINE_CHUNK")) {
+                const int f = atoi(e);
+                if (f >= 1 && f <= 64) ac = f;
+            }
+            const size_t lanes = ((cnt + ac - 1) / ac + 63) & ~(size_t)63;
+            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt, ac);
+        } else {
+            hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
+        }
         HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
         // bucket sums: segmented reduction of the sorted list in runs of T, level by level
         {
-            const zc::u32* lk = kb.current();
+            const zc::u32* lk = nullptr;
             const zc::u32* lr = nullptr;
             size_t len = m;
             for (int level = 0;; level++) {
@@ -581,7 +661,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 zc::u32* nk = ekeys[level & 1];
                 zc::u32* nr = erecs[level & 1];
                 if (level == 0)
-                    hipLaunchKernelGGL(zc::k_msm_runs, dim3((unsigned)((nl + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), 0, D.s(), lk, (const zc::u32*)vb.current(), (const zc::u32*)cached,
+                    hipLaunchKernelGGL(affine ? zc::k_msm_runs_affine : zc::k_msm_runs, dim3((unsigned)((nl + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), 0, D.s(), sorted, (const zc::u32*)cached,
                                        (zc::u32)len, (zc::u32)t, (zc::u32)nb, buckets, present, nk, nr);
                 else
                     hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
@@ -1308,6 +1388,44 @@ int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t 
     HIP_TRY(hipSetDevice(owner->device));
     HIP_TRY(hipMemcpyAsync(out_point, res, 160, hipMemcpyDeviceToHost, owner->s()));
     HIP_TRY(hipStreamSynchronize(owner->s()));
+    return ZC_OK;
+}
+
+// Test hook, NOT part of the ABI (not in include/zerocaf_hip.h, not mirrored): the MSM's digit + sort stage alone.
+// `scalars` (n x 5 u64) and `out_pairs` (n * ceil(261 / c) pairs of u32: bucket key, point index | sign << 31)
+// are DEVICE buffers of ctx's device slot 0; synchronises before returning.
+int zc_test_msm_sort(zc_ctx* ctx, const uint64_t* scalars, size_t n, int c, uint32_t* out_pairs)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(scalars); REQUIRE(out_pairs);
+    if (c < zc::MSM_MIN_C || c > zc::MSM_MAX_C || n == 0) return fail(ZC_ERR_BAD_ARG, "zc_test_msm_sort: bad window width / empty batch");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DevState& D = ctx->devs[0];
+    HIP_TRY(hipSetDevice(D.device));
+    const int W = (zc::MSM_SCALAR_BITS + c - 1) / c;
+    const size_t m = n * (size_t)W;
+    if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_test_msm_sort: too many pairs");
+    const MsmSortPlan plan = msm_sort_plan(n, c, W);
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv{pass ? (char*)D.msm : nullptr};
+        zc::u32* digits = cv.take<zc::u32>(m);
+        uint2* pairs_a = cv.take<uint2>(m);
+        uint2* pairs_b = plan.passes > 1 ? cv.take<uint2>(m) : nullptr;
+        zc::u32* table = cv.take<zc::u32>(plan.table_words);
+        zc::u32* sums = cv.take<zc::u32>(plan.table_words / zc::SCAN_BLOCK_ELEMS + 1);
+        if (!pass) {
+            int rc = ensure(&D.msm, &D.msm_bytes, cv.off);
+            if (rc) return rc;
+            continue;
+        }
+        hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(n)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)scalars, digits, n, c, W);
+        const uint2* sorted = nullptr;
+        int rc = msm_sort(D, plan, digits, pairs_a, pairs_b, table, sums, &sorted);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_pairs, sorted, m * sizeof(uint2), hipMemcpyDeviceToDevice, D.s()));
+        HIP_TRY(hipStreamSynchronize(D.s()));
+        HIP_TRY(hipGetLastError());
+    }
     return ZC_OK;
 }
 

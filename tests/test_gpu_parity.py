@@ -816,6 +816,63 @@ def test_msm_degenerate_scalars(eng, oracle):
     assert eq(oracle.ed_compress(eng.msm(P, K))[0], oracle.ed_compress(_gpu_naive_msm(eng, P, K))[0])
 
 
+def _msm_sort_model(K, c):
+    """numpy model of k_msm_digits + the bucket sort: pairs (window << (c-1) | |d| - 1, i | sign << 31) in
+    stable bucket order, the zero digits (key 0xFFFFFFFF) behind every bucket, window by window."""
+    n, W, half = len(K), -(-261 // c), 1 << (c - 1)
+    key = np.zeros((W, n), dtype=np.int64)
+    sign = np.zeros((W, n), dtype=np.uint32)
+    for i in range(n):
+        v = sum(int(K[i, j]) << (52 * j) for j in range(5))
+        carry = 0
+        for w in range(W):
+            raw = ((v >> (w * c)) & ((1 << c) - 1)) + carry
+            carry = 1 if raw > half else 0
+            mag = (1 << c) - raw if carry else raw
+            key[w, i] = (w << (c - 1)) | (mag - 1) if mag else -1
+            sign[w, i] = carry
+    idx = np.arange(n, dtype=np.uint32)
+    out_k, out_v, tail_k, tail_v = [], [], [], []
+    for w in range(W):
+        nz = key[w] >= 0
+        order = np.argsort(key[w][nz], kind="stable")
+        out_k.append(key[w][nz][order].astype(np.uint32))
+        out_v.append((idx[nz] | (sign[w][nz] << np.uint32(31)))[order])
+        tail_k.append(np.full(int((~nz).sum()), 0xFFFFFFFF, dtype=np.uint32))
+        tail_v.append(idx[~nz] | (sign[w][~nz] << np.uint32(31)))       # raw = 2^c: a zero digit that still carries
+    return np.concatenate(out_k + tail_k), np.concatenate(out_v + tail_v)
+
+
+@pytest.mark.parametrize("n,c,g", [(1000, 5, None), (3 * 4096 + 17, 9, None), (3 * 4096 + 17, 10, 2), (70001, 13, None),
+                                   (70001, 17, 3), (40000, 19, None), (20000, 20, None), (9000, 22, 1)])
+def test_msm_key_sort_is_the_stable_bucket_order(eng, n, c, g, monkeypatch):
+    """The hand-written per-window LSD counting sort (zc_sort.hip.h) through its test hook: one, two and three
+    passes, partial tiles, several tiles per column, skewed digits -- pair for pair the stable sort's output."""
+    import ctypes as C
+    import torch
+    if g is None:
+        monkeypatch.delenv("ZC_MSM_SORT_G", raising=False)
+    else:
+        monkeypatch.setenv("ZC_MSM_SORT_G", str(g))
+    fn = eng.lib.zc_test_msm_sort
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    fn.restype = C.c_int
+    K = V.rand_scalars_np(n, V.SEED + 300 + c, bits=252)
+    K[0] = 0
+    K[1] = [(1 << 52) - 1] * 5                                    # all 260 bits: the recoding carry reaches the top window
+    K[n // 2:n // 2 + n // 8] = K[5]                              # a skewed stretch: equal scalars
+    K[-7:, 2:] = 0                                                # short scalars: zero digits in the upper windows
+    W = -(-261 // c)
+    dK = torch.from_numpy(K.view(np.int64)).cuda()
+    out = torch.empty((n * W, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert fn(eng.ctx, dK.data_ptr(), n, c, out.data_ptr()) == 0, eng.lib.zc_last_error()
+    got = out.cpu().numpy().view(np.uint32)
+    wk, wv = _msm_sort_model(K, c)
+    assert eq(got[:, 0], wk)
+    assert eq(got[:, 1], wv)
+
+
 def _gpu_naive_msm(eng, P, K):
     """sum_i k_i P_i through separately-tested kernels: batched scalar-mul, then pairwise adds."""
     q = eng.ed_scalar_mul(P, K)
