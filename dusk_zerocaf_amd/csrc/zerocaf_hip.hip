@@ -491,6 +491,9 @@ int msm_window_bits(size_t cnt)
 // G = 4; 2^24: G = 16), which bounds the table (windows x bins x columns words) at a few MB.
 struct MsmSortPlan {
     int passes = 0;
+    bool packed = false;                                      // two passes with the one-word intermediate (zc_sort.hip.h):
+                                                              // sign | high digit bits + the zero-digit flag | point index fit 32 bits
+    bool big = false;                                         // tiles of 8192 keys
     zc::msm_sort_pass pass[4];
     size_t table_words = 0;                                   // largest table, padded to whole scan blocks
 };
@@ -499,7 +502,15 @@ MsmSortPlan msm_sort_plan(size_t n, int c, int W)
     MsmSortPlan pl;
     const int B = c - 1;
     pl.passes = (B + zc::MSM_SORT_PASS_BITS - 1) / zc::MSM_SORT_PASS_BITS;
-    const size_t ntiles = (n + zc::MSM_SORT_TILE - 1) / zc::MSM_SORT_TILE;
+    // two-word records of large batches: tiles of 8192 keys (ZC_MSM_SORT_BIG=0/1 forces the choice)
+    int idx_bits = 1;
+    while (((size_t)1 << idx_bits) < n) idx_bits++;
+    const char* pe = getenv("ZC_MSM_SORT_PACKED");
+    pl.packed = pl.passes == 2 && 1 + (B - (B + 1) / 2) + 1 + idx_bits <= 32 && !(pe && atoi(pe) == 0);
+    pl.big = !pl.packed && n >= ((size_t)1 << 22);
+    if (const char* e = getenv("ZC_MSM_SORT_BIG")) pl.big = !pl.packed && atoi(e) != 0;
+    const size_t tile = (size_t)zc::ZC_BLOCK * (pl.big ? zc::MSM_SORT_KPT_BIG : zc::MSM_SORT_KPT);
+    const size_t ntiles = (n + tile - 1) / tile;
     size_t G = ntiles / 128;
     G = std::max<size_t>(1, std::min<size_t>(16, G));
     if (const char* e = getenv("ZC_MSM_SORT_G")) {
@@ -513,38 +524,50 @@ MsmSortPlan msm_sort_plan(size_t n, int c, int W)
         zc::msm_sort_pass& p = pl.pass[i];
         p.n = (zc::u32)n;
         p.W = (zc::u32)W;
+        p.tile = (zc::u32)tile;
         p.G = (zc::u32)G;
         p.ncols = (zc::u32)ncols;
         p.shift = (zc::u32)shift;
         p.bits = (zc::u32)bits;
         p.last = i + 1 == pl.passes ? 1u : 0u;
         p.c = (zc::u32)c;
+        p.idx_bits = pl.packed ? (zc::u32)idx_bits : 0;
         shift += bits;
         const size_t words = ((size_t)W * ((size_t)1 << bits) + (p.last ? (size_t)W : 0)) * ncols;
         pl.table_words = std::max(pl.table_words, (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS);
     }
     return pl;
 }
-// digits (window-major words in `digits`) -> pairs ordered by bucket; returns the buffer that holds them
-int msm_sort(DevState& D, const MsmSortPlan& pl, const zc::u32* digits, uint2* buf_a, uint2* buf_b, zc::u32* table, zc::u32* sums, const uint2** sorted)
+// digits (window-major words in `digits`) -> pairs ordered by bucket in *sorted (buf_a or buf_b).  buf_b holds m
+// pairs, or m words when the plan is packed; `tables` = two tables of pl.table_words words.
+int msm_sort(DevState& D, const MsmSortPlan& pl, const zc::u32* digits, uint2* buf_a, void* buf_b, zc::u32* tables, zc::u32* sums, const uint2** sorted)
 {
     const zc::u32* in = digits;
-    uint2* out = buf_a;
+    // the last pass writes buf_a; the passes before it alternate so that no pass reads what it writes
+    void* out = (pl.passes & 1) ? (void*)buf_a : buf_b;
     for (int i = 0; i < pl.passes; i++) {
         const zc::msm_sort_pass& p = pl.pass[i];
+        zc::u32* table = tables + (size_t)(i & 1) * pl.table_words;
         const size_t words = ((size_t)p.W * ((size_t)1 << p.bits) + (p.last ? (size_t)p.W : 0)) * p.ncols;
         const size_t padded = (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS;
         const unsigned nblk = (unsigned)(padded / zc::SCAN_BLOCK_ELEMS), grid = (unsigned)(p.W * p.ncols);
         if (padded > words) HIP_TRY(hipMemsetAsync(table + words, 0, (padded - words) * sizeof(zc::u32), D.s()));
-        hipLaunchKernelGGL(i ? zc::k_msm_sort_hist_pairs : zc::k_msm_sort_hist, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, table, p);
+        hipLaunchKernelGGL(!i ? zc::k_msm_sort_hist : pl.packed ? zc::k_msm_sort_hist_packed : zc::k_msm_sort_hist_pairs, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, table, p);
         hipLaunchKernelGGL(zc::k_scan_reduce, dim3(nblk), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)table, sums);
         hipLaunchKernelGGL(zc::k_scan_sums, dim3(1), dim3(zc::ZC_BLOCK), 0, D.s(), sums, (zc::u32)nblk);
         hipLaunchKernelGGL(zc::k_scan_apply, dim3(nblk), dim3(zc::ZC_BLOCK), 0, D.s(), table, (const zc::u32*)sums);
-        hipLaunchKernelGGL(i ? zc::k_msm_sort_scatter_pairs : zc::k_msm_sort_scatter, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, out, (const zc::u32*)table, p);
+        if (pl.packed && i == 0)
+            hipLaunchKernelGGL(zc::k_msm_sort_scatter_pack, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, (zc::u32*)out, (const zc::u32*)table, p);
+        else if (pl.packed)
+            hipLaunchKernelGGL(zc::k_msm_sort_scatter_unpack, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, (uint2*)out, (const zc::u32*)table,
+                               (const zc::u32*)(tables + (size_t)((i - 1) & 1) * pl.table_words), p);
+        else
+            hipLaunchKernelGGL(pl.big ? (i ? zc::k_msm_sort_scatter_pairs_big : zc::k_msm_sort_scatter_big) : (i ? zc::k_msm_sort_scatter_pairs : zc::k_msm_sort_scatter),
+                               dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, (uint2*)out, (const zc::u32*)table, p);
         in = reinterpret_cast<const zc::u32*>(out);
-        *sorted = out;
-        out = out == buf_a ? buf_b : buf_a;
+        out = out == (void*)buf_a ? buf_b : (void*)buf_a;
     }
+    *sorted = buf_a;
     return ZC_OK;
 }
 
@@ -612,8 +635,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         Carver cv{pass ? (char*)D.msm : nullptr};
         zc::u32* digits = cv.take<zc::u32>(m);
         uint2* pairs_a = cv.take<uint2>(m);
-        uint2* pairs_b = plan.passes > 1 ? cv.take<uint2>(m) : nullptr;
-        zc::u32* sort_table = cv.take<zc::u32>(plan.table_words);
+        void* pairs_b = plan.passes == 1 ? nullptr : plan.packed ? (void*)cv.take<zc::u32>(m) : (void*)cv.take<uint2>(m);
+        zc::u32* sort_table = cv.take<zc::u32>(2 * plan.table_words);
         zc::u32* sort_sums = cv.take<zc::u32>(plan.table_words / zc::SCAN_BLOCK_ELEMS + 1);
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
@@ -1410,8 +1433,8 @@ int zc_test_msm_sort(zc_ctx* ctx, const uint64_t* scalars, size_t n, int c, uint
         Carver cv{pass ? (char*)D.msm : nullptr};
         zc::u32* digits = cv.take<zc::u32>(m);
         uint2* pairs_a = cv.take<uint2>(m);
-        uint2* pairs_b = plan.passes > 1 ? cv.take<uint2>(m) : nullptr;
-        zc::u32* table = cv.take<zc::u32>(plan.table_words);
+        void* pairs_b = plan.passes == 1 ? nullptr : plan.packed ? (void*)cv.take<zc::u32>(m) : (void*)cv.take<uint2>(m);
+        zc::u32* table = cv.take<zc::u32>(2 * plan.table_words);
         zc::u32* sums = cv.take<zc::u32>(plan.table_words / zc::SCAN_BLOCK_ELEMS + 1);
         if (!pass) {
             int rc = ensure(&D.msm, &D.msm_bytes, cv.off);

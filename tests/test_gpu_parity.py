@@ -843,17 +843,21 @@ def _msm_sort_model(K, c):
     return np.concatenate(out_k + tail_k), np.concatenate(out_v + tail_v)
 
 
-@pytest.mark.parametrize("n,c,g", [(1000, 5, None), (3 * 4096 + 17, 9, None), (3 * 4096 + 17, 10, 2), (70001, 13, None),
-                                   (70001, 17, 3), (40000, 19, None), (20000, 20, None), (9000, 22, 1)])
-def test_msm_key_sort_is_the_stable_bucket_order(eng, n, c, g, monkeypatch):
+@pytest.mark.parametrize("n,c,g,packed", [(1000, 5, None, 1), (3 * 4096 + 17, 9, None, 1), (3 * 4096 + 17, 10, 2, 1), (3 * 4096 + 17, 10, 2, 0),
+                                          (70001, 13, None, 1), (70001, 17, 3, 1), (70001, 17, 3, 0), (40000, 19, None, 1),
+                                          (40000, 19, 2, 0), (40000, 19, 2, 2), (3 * 8192 + 5, 9, 2, 2), (20000, 20, None, 1), (9000, 22, 1, 1)])
+def test_msm_key_sort_is_the_stable_bucket_order(eng, n, c, g, packed, monkeypatch):
     """The hand-written per-window LSD counting sort (zc_sort.hip.h) through its test hook: one, two and three
-    passes, partial tiles, several tiles per column, skewed digits -- pair for pair the stable sort's output."""
+    passes, the one-word and the two-word intermediate of the two-pass sort, partial tiles, several tiles per
+    column, skewed digits -- pair for pair the stable sort's output."""
     import ctypes as C
     import torch
     if g is None:
         monkeypatch.delenv("ZC_MSM_SORT_G", raising=False)
     else:
         monkeypatch.setenv("ZC_MSM_SORT_G", str(g))
+    monkeypatch.setenv("ZC_MSM_SORT_PACKED", "1" if packed == 1 else "0")      # 0: two-word intermediate, 2: with tiles of 8192 keys
+    monkeypatch.setenv("ZC_MSM_SORT_BIG", "1" if packed == 2 else "0")
     fn = eng.lib.zc_test_msm_sort
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     fn.restype = C.c_int
