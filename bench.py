@@ -19,18 +19,22 @@ Prints ONE JSON line on rank 0.
 
 roofline: the scalar-mul / Ristretto / MSM kernels are bound by the integer multiplier pipe
 (v_mad_u64_u32 class), not by HBM (0.2 % of 8 TB/s), so `bound` = "valu_int_mul":
-  achieved = multiplier-rate-class lane-operations per second the kernel issued
-           = PMC SQ_INSTS_VALU per unit (profiles/roofline_inputs.json) x units x the class's share of
-             the loop's VALU instructions (tools/isa_mix.py) x 64 lanes / kernel time (HIP events, live)
+  achieved = USEFUL v_mad_u64_u32 lane-operations per second: the multiplications the algorithm needs x 135 per
+             Montgomery multiplication / kernel time (HIP events, live) -- no profile input at all.  Strict scalar-mul:
+             sum over this run's scalars of (bitlen - 1 + popcount) evaluations of the reference's addition formula x 9
+             multiplications; MSM: non-zero window digits x 7 multiplications (the mixed addition of the bucket sums);
+             Ristretto round trip: the windowed core's fixed schedule + the two codecs.
   peak     = one multiplier-class wave-instruction per 4 shader cycles per SIMD at the nominal clock (a hard
              roof: 39.3 T lane-ops/s); `measured_rate` = the saturated v_mad_u64_u32 rate of this board measured
              in this run (libzc_ubench.so), with the same fractions against it
-`frac_useful` counts only the multiplications the reference's formula sequence needs (computed from
-the actual scalars of this run: sum of bitlen - 1 + popcount formula evaluations x 9 multiplications
-x 135 v_mad_u64_u32) -- no profile input at all.  The PMC-derived fields are dropped (null, with a
-note) when the profile was taken on other kernel sources than the loaded library was built from (sha256 of
-csrc/ + the header, embedded in zc_version()).  The HBM view
-(algorithmic bytes / time vs 8 TB/s, PMC traffic) is kept under `hbm`.  fe_mul is HBM-bound: `bound` = "hbm".
+  frac     = achieved / peak (useful work only).  `frac_issued` = every multiplier-class instruction the kernel
+             issued (PMC SQ_INSTS_VALU per unit from profiles/roofline_inputs.json x the class's share of the
+             loop's VALU instructions, tools/isa_mix.py): reduction bookkeeping, carry shifts and lost wave steps
+             included.  The PMC-derived fields are dropped (null, with a note) when the profile was taken on other
+             kernel sources than the loaded library was built from (sha256 of csrc/ + the header, in zc_version()).
+The HBM view (algorithmic bytes / time vs 8 TB/s, PMC traffic) is kept under `hbm`.  fe_mul is HBM-bound:
+`bound` = "hbm" (tagged `cache_resident` when the launch's arrays fit the 256 MB Infinity Cache: then the figure
+is cache bandwidth, not HBM).  fe_invert is neither: `bound` = "latency/occupancy" with the resident waves per SIMD.
 """
 from __future__ import annotations
 
@@ -52,11 +56,47 @@ WORKLOADS = {
     # algorithmic bytes per unit: SURVEY 8(d)
     "scalar_mul": {"bytes": 360, "kernel": "k_ed_scalar_mul_pw (+ k_sm_cost_hist/scan/scatter)", "bound": "valu_int_mul", "unit": "scalar-muls/s"},
     "fe_mul": {"bytes": 120, "kernel": "k_fe_mul", "bound": "hbm", "unit": "field-muls/s"},
-    "fe_invert": {"bytes": 80, "kernel": "k_fe_invert_chunked", "bound": "hbm", "unit": "field-inversions/s"},
+    "fe_invert": {"bytes": 80, "kernel": "k_fe_invert_chunked", "bound": "latency/occupancy", "unit": "field-inversions/s"},
     "ristretto": {"bytes": 104, "kernel": "k_ris_roundtrip_mul_fast", "bound": "valu_int_mul", "unit": "round-trips/s"},
-    "msm": {"bytes": 200, "kernel": "k_msm_runs (+ rocPRIM radix sort, k_msm_prepare/digits/runs_edges/segments/fold_groups/window_combine)",
+    "msm": {"bytes": 200, "kernel": "k_msm_runs_affine (+ k_msm_digits, k_msm_sort_hist/scatter + k_scan_*, k_msm_prepare_affine, k_msm_runs_edges/segments/fold_groups/window_combine)",
             "bound": "valu_int_mul", "unit": "pairs/s"},
 }
+INFINITY_CACHE_BYTES = 256 << 20
+HBM_COPY_GBS = 6290.0            # MI355X_MICROARCH.md: what a device-to-device copy reaches (the achievable HBM rate)
+
+
+def msm_window_bits(n):
+    """The window width zc_msm picks for a shard of n pairs (zerocaf_hip.hip: msm_window_bits)."""
+    c = max(5, n.bit_length() - 1 - 4)
+    if c in (15, 16):
+        c = 17
+    c = min(c, 19)
+    e = os.environ.get("ZC_MSM_WINDOW")
+    if e and 5 <= int(e) <= 22:
+        c = int(e)
+    return c
+
+
+def msm_nonzero_digits(K, c):
+    """Number of non-zero signed c-bit window digits over all scalars (k_msm_digits' recoding): the bucket additions an
+    MSM of these scalars cannot avoid."""
+    n = len(K)
+    W = -(-261 // c)
+    carry = np.zeros(n, dtype=np.uint64)
+    half, mask, total = np.uint64(1 << (c - 1)), np.uint64((1 << c) - 1), 0
+    for w in range(W):
+        bit = w * c
+        idx, sh = bit // 52, bit % 52
+        if idx >= 5:
+            raw = carry.copy()
+        else:
+            x = K[:, idx] >> np.uint64(sh)
+            if sh + c > 52 and idx + 1 < 5:
+                x = x | (K[:, idx + 1] << np.uint64(52 - sh))
+            raw = (x & mask) + carry
+        carry = (raw > half).astype(np.uint64)
+        total += int(np.count_nonzero(raw != carry * np.uint64(1 << c)))
+    return total, W
 
 
 def log(*a):
@@ -240,6 +280,56 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_s = sum(kern_ms) / len(kern_ms) * 1e-3
 
+    # what makes a multi-GPU line self-proving: which physical device every rank ran on (N distinct ones), the rank
+    # count RCCL itself reports for the library's communicator, and every rank's own kernel time (a straggler shows)
+    pr = torch.cuda.get_device_properties(local)
+    ident = {"rank": rank, "local_device": local, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+             "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+             "kernel_avg_ms": round(kern_avg_s * 1e3, 4)}
+    rccl_ranks = None
+    if wl == "msm" and (backend == "nccl" or world == 1):
+        rccl_ranks = eng.comm_size()
+        ident["rccl_ranks"] = rccl_ranks
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    shared_device_hook = bool(os.environ.get("ZC_BENCH_DEVICE"))
+    distinct = len({(d["uuid"], d["pci"]) for d in idents})
+    if world > 1 and not shared_device_hook and distinct != world:
+        raise SystemExit("bench.py: %d ranks but only %d distinct devices: %s" % (world, distinct, idents))
+    if rccl_ranks is not None and backend == "nccl" and any(d.get("rccl_ranks") != world for d in idents):
+        raise SystemExit("bench.py: the library's RCCL communicator does not span %d ranks: %s" % (world, idents))
+
+    # config 5, fail closed: the timed result must be the ordered fold of the ranks' own partial sums (zc_msm_partial ->
+    # torch.distributed all-gather -> zc_ed_fold_ordered: another route than the in-library exchange), and each rank's
+    # partial must be the ordered fold of the partial sums of its eight contiguous sub-ranges
+    msm_fold_ok = None
+    if wl == "msm":
+        part = eng.msm_partial(data["P"], data["K"])
+        per = -(-n // 8)
+        sub = torch.cat([eng.msm_partial(data["P"][lo:lo + per], data["K"][lo:lo + per]) for lo in range(0, n, per)])
+        refold = eng.ed_fold_ordered(sub)
+        torch.cuda.synchronize()
+        same = lambda a, b: bool(eng.ed_eq(a, b).cpu().numpy()[0] == 1 and
+                                 np.array_equal(eng.ed_compress(a)[0].cpu().numpy(), eng.ed_compress(b)[0].cpu().numpy()))
+        msm_fold_ok = same(part, refold)
+        rows = part
+        if world > 1:
+            if backend == "nccl":
+                rows = D.all_gather_rows(part)
+            else:
+                rows = torch.from_numpy(D.all_gather_rows(part.cpu().numpy().view(np.uint64)).view(np.int64)).cuda()
+        total_pt = eng.ed_fold_ordered(rows)
+        timed = torch.from_numpy(np.ascontiguousarray(msm_result[0]).view(np.int64)).cuda()
+        msm_fold_ok = msm_fold_ok and same(total_pt, timed)
+        if world > 1:
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(msm_fold_ok))
+            msm_fold_ok = all(flags)
+        if not msm_fold_ok:
+            raise SystemExit("PARITY FAILURE: the timed MSM result is not the ordered fold of the shard partials")
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -259,15 +349,29 @@ def main():
         hbm["traffic_source"] = inp.get("source")
     roofline = {"bound": W["bound"], "kernel": W["kernel"] if kkey != "scalar_mul_fast" else "k_ed_scalar_mul_fast",
                 "kernel_avg_ms": round(kern_avg_s * 1e3, 4)}
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
     if W["bound"] == "hbm":
         roofline.update({k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_unit")})
+        # the arrays of one launch against the 256 MB Infinity Cache: below it the launches of a benchmark loop find
+        # their inputs in the cache and `achieved` is cache bandwidth, not HBM
+        roofline["cache_resident"] = bool(W["bytes"] * n <= INFINITY_CACHE_BYTES)
+        if roofline["cache_resident"]:
+            roofline["note"] = "%d MB per launch fit the 256 MB Infinity Cache: cache bandwidth, not an HBM figure (the HBM line is --units 16777216)" % (W["bytes"] * n >> 20)
+    elif W["bound"] == "latency/occupancy":
+        # fe_invert: one division-step inversion per lane shared by c elements (Montgomery's trick); at 2^20 elements
+        # only half a wave per SIMD is resident, so neither HBM nor the multiplier is the limit
+        c = min(32, n // 65536)
+        lanes = n if c < 2 else -(-n // c)
+        roofline.update({"achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": hbm["traffic"],
+                         "algorithmic_bytes_per_unit": W["bytes"], "elements_per_lane": max(1, c), "lanes": lanes,
+                         "resident_waves_per_simd": round(lanes / 64 / (props.multi_processor_count * 4), 3),
+                         "note": "latency / occupancy bound: the figures are the HBM view for reference only; see DESIGN 4.2"})
     else:
         # peak: a v_mad_u64_u32-class wave-instruction cannot issue faster than once per 4 shader cycles per
         # SIMD (the best ever measured on this chip is 4.4, tools/ubench/occupancy.hip), priced at the
         # nominal clock: CUs x 4 SIMDs x 64 lanes x f_max / 4.  A hard roof; the board never holds f_max
         # under this load, so the saturated rate MEASURED in this very run (libzc_ubench.so, same board, same
         # thermal state, right after the timed region) is reported beside it with its own fraction.
-        props = torch.cuda.get_device_properties(torch.cuda.current_device())
         f_max = (getattr(props, "clock_rate", 0) or 2400000) * 1e3
         peak = round(props.multi_processor_count * 4 * 64 * f_max / 4 / 1e12, 2)
         measured = None
@@ -287,21 +391,15 @@ def main():
         if measured is None and (inp or {}).get("ubench", {}).get("v_mad_u64_u32_T_lane_ops_per_s"):
             measured = {"v_mad_u64_u32_T_lane_ops_per_s": inp["ubench"]["v_mad_u64_u32_T_lane_ops_per_s"],
                         "source": str(inp["ubench"].get("source")) + " (another run / board: libzc_ubench.so not built)"}
-        roofline.update({"achieved": None, "peak": peak, "unit": "T lane-ops/s (v_mad_u64_u32-rate instruction class, 64 lanes per wave-instruction)",
+        roofline.update({"achieved": None, "peak": peak, "unit": "T lane-ops/s (v_mad_u64_u32, 64 lanes per wave-instruction)",
                          "frac": None, "traffic": hbm["traffic"], "hbm": hbm,
                          "peak_basis": "one multiplier-class wave-instruction per 4 shader cycles per SIMD at the nominal %.1f GHz" % (f_max / 1e9),
                          "measured_rate": measured})
-        if peak and kin.get("valu_insts_per_unit") and kin.get("multiplier_rate_share"):
-            lane_ops = kin["valu_insts_per_unit"] * n * kin["multiplier_rate_share"] * 64
-            roofline["achieved"] = round(lane_ops / kern_avg_s / 1e12, 3)
-            roofline["frac"] = round(roofline["achieved"] / peak, 4)
-            roofline["inputs"] = {"source": inp.get("source"), "valu_wave_insts_per_unit": kin["valu_insts_per_unit"],
-                                  "multiplier_rate_share": kin["multiplier_rate_share"]}
-            if measured:
-                measured["frac"] = round(roofline["achieved"] / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
-        if peak and wl == "scalar_mul" and args.mode == "strict":
-            # useful work only, from this run's scalars: sum over elements of (bitlen - 1 + popcount)
-            # evaluations of the reference's addition formula, 9 multiplications of 135 v_mad_u64_u32 each
+        # ---- useful work: the multiplications the algorithm needs, from this run's own inputs (no profile)
+        useful, basis = None, None
+        if wl == "scalar_mul" and args.mode == "strict":
+            # sum over elements of (bitlen - 1 + popcount) evaluations of the reference's addition formula,
+            # 9 multiplications of 135 v_mad_u64_u32 each
             K = data["host_K"]
             bits = np.zeros(n, dtype=np.int64)
             pop = np.zeros(n, dtype=np.int64)
@@ -314,15 +412,52 @@ def main():
                 pop += np.array([bin(int(v)).count("1") for v in x]) if n <= 4096 else _popcount64(x)
             evals = int(np.sum(np.where(bits > 0, bits - 1 + pop, 0)))
             useful = evals * 9 * MADS_PER_MUL
-            roofline["useful"] = {"formula_evaluations_per_unit": round(evals / n, 2), "v_mad_u64_u32_lane_ops": useful,
-                                  "achieved": round(useful / kern_avg_s / 1e12, 3)}
-            roofline["frac_useful"] = round(useful / kern_avg_s / 1e12 / peak, 4)
+            basis = {"formula_evaluations_per_unit": round(evals / n, 2), "multiplications_per_evaluation": 9}
+        elif wl == "scalar_mul":
+            # windowed core: 63 four-bit windows of (3 x (4S + 3M) + (4S + 4M) doublings + one 8M addition) + the 55M table
+            useful = n * (63 * (4 * (4 * 99 + 3 * 135) + 135 + 8 * 135) + 55 * 135)
+            basis = {"windows": 63, "v_mad_u64_u32_per_window": 4 * (4 * 99 + 3 * 135) + 135 + 8 * 135}
+        elif wl == "ristretto":
+            # the same core between one decompression and one compression (one (p-5)/8 power each: ~250 squarings + ~36
+            # multiplications, + ~25 multiplications of glue)
+            codec = 250 * 99 + 61 * 135
+            useful = n * (63 * (4 * (4 * 99 + 3 * 135) + 135 + 8 * 135) + 55 * 135 + 2 * codec)
+            basis = {"windows": 63, "v_mad_u64_u32_per_window": 4 * (4 * 99 + 3 * 135) + 135 + 8 * 135, "v_mad_u64_u32_per_codec": codec}
+        elif wl == "msm":
+            c_bits = msm_window_bits(n)
+            digits, nwin = msm_nonzero_digits(data["host_K"], c_bits)
+            useful = digits * 7 * MADS_PER_MUL               # one 7-multiplication mixed addition per non-zero digit
+            basis = {"window_bits": c_bits, "windows": nwin, "nonzero_digits_per_pair": round(digits / n, 3), "multiplications_per_bucket_addition": 7,
+                     "note": "bucket reduction, window combination and the affine normalisation are overhead, not counted"}
+        if useful is not None:
+            roofline["achieved"] = round(useful / kern_avg_s / 1e12, 3)
+            roofline["frac"] = round(useful / kern_avg_s / 1e12 / peak, 4)
+            roofline["useful"] = dict(basis, v_mad_u64_u32_lane_ops=useful)
             if measured:
-                measured["frac_useful"] = round(useful / kern_avg_s / 1e12 / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
-            if roofline["frac"] is None:
-                roofline["frac"] = roofline["frac_useful"]
-                roofline["achieved"] = roofline["useful"]["achieved"]
-                roofline["note"] = "frac = useful multiplications only (no matching PMC profile for this build)"
+                measured["frac"] = round(useful / kern_avg_s / 1e12 / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
+        # ---- issued work: every multiplier-class instruction (PMC x ISA share), only with a profile of THIS build
+        if peak and kin.get("valu_insts_per_unit") and kin.get("multiplier_rate_share"):
+            lane_ops = kin["valu_insts_per_unit"] * n * kin["multiplier_rate_share"] * 64
+            roofline["issued"] = {"achieved": round(lane_ops / kern_avg_s / 1e12, 3), "source": inp.get("source"),
+                                  "valu_wave_insts_per_unit": kin["valu_insts_per_unit"], "multiplier_rate_share": kin["multiplier_rate_share"],
+                                  "kernels_counted": kin.get("kernels_counted")}
+            roofline["frac_issued"] = round(roofline["issued"]["achieved"] / peak, 4)
+            if measured:
+                measured["frac_issued"] = round(roofline["issued"]["achieved"] / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
+        if wl == "msm":
+            # the gathers of the bucket sums: one cached record per non-zero digit, random over the record array
+            rec = 96 if n >= (1 << 17) else 128
+            g = {"record_bytes": rec, "records": basis["nonzero_digits_per_pair"] * n, "unit": "GB/s", "peak": HBM_COPY_GBS,
+                 "peak_basis": "what a device copy reaches (MI355X_MICROARCH.md); random %d-byte gathers" % rec}
+            share = kin.get("runs_time_share")
+            if share:
+                g["achieved"] = round(rec * digits / (kern_avg_s * share) / 1e9, 1)
+                g["frac"] = round(g["achieved"] / HBM_COPY_GBS, 4)
+                g["runs_time_share"] = share
+                g["source"] = inp.get("source")
+                if roofline["frac"] is not None and g["frac"] > roofline["frac"]:
+                    roofline["bound"] = "gather"
+            roofline["gather"] = g
         if stale:
             roofline["profile_note"] = stale
 
@@ -334,6 +469,7 @@ def main():
         per_core = {"scalar_mul": 1 << 13, "ristretto": 1 << 12, "fe_mul": 1 << 24, "fe_invert": 1 << 16, "msm": 1 << 13}[wl]
         sample = per_core * _z.host_threads() if world == 1 else {"fe_mul": 1 << 16, "fe_invert": 1 << 14}.get(wl, 1 << 11)   # N > 1: parity check only
     if sample:
+        from oracle import zc_ref
         v, cores, secs, total, want = cpu_baseline(wl, sample, data, n)
         k = 0 if wl == "msm" else min(len(want[0] if wl in ("ristretto", "fe_invert") else want), n)
         if wl == "scalar_mul":
@@ -359,11 +495,12 @@ def main():
         else:
             # MSM: the GPU sum over the first `total` pairs against the oracle's sum of the same pairs,
             # compared as canonical encodings (zc_msm contract: a group element)
-            from oracle import zc_ref
             sub = eng.msm(data["P"][:total], data["K"][:total])
             checked = bool(np.array_equal(zc_ref.ed_compress(sub)[0], zc_ref.ed_compress(want)[0]) and zc_ref.ed_eq(sub, want)[0] == 1)
             if total == n and world == 1:
                 checked = checked and bool(np.array_equal(zc_ref.ed_compress(msm_result[0])[0], zc_ref.ed_compress(want)[0]))
+            # beyond the oracle's sample the timed result was checked above as the ordered fold of the shard partials
+            checked = checked and bool(msm_fold_ok)
         if not checked:
             raise SystemExit("PARITY FAILURE: GPU result differs from the oracle")
         what = {"scalar_mul": "zr_ed_scalar_mul (double_and_add)", "fe_mul": "zr_fe_mul", "fe_invert": "zr_fe_inverse (Savas-Koc, field.rs:854-925)", "ristretto": "zr_ris_roundtrip_mul (decompress, double_and_add, compress)",
@@ -372,14 +509,32 @@ def main():
             model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             model = "unknown CPU"
+        single = None
+        if baseline_leg and cores > 1:
+            # the measured one-thread leg: the same operation on 1 / cores of the sample, one host thread
+            m1 = max(1, total // cores)
+            host1 = lambda t: np.ascontiguousarray(t[:m1].cpu().numpy()).view(np.uint64)
+            t1 = time.perf_counter()
+            if wl == "fe_mul":
+                zc_ref.fe_mul(data["host"][0][:m1], data["host"][1][:m1])
+            elif wl == "fe_invert":
+                zc_ref.fe_invert(data["host"][0][:m1])
+            elif wl == "scalar_mul":
+                zc_ref.ed_scalar_mul(host1(data["P"]), data["host_K"][:m1])
+            elif wl == "ristretto":
+                zc_ref.ris_roundtrip_mul(data["enc"][:m1].cpu().numpy(), data["host_K"][:m1])
+            else:
+                zc_ref.msm_naive(host1(data["P"]), data["host_K"][:m1])
+            single = {"value": round(m1 / (time.perf_counter() - t1), 1), "units": m1}
         cpu = None if not baseline_leg else {"value": round(v, 1), "unit": W["unit"], "cores": cores, "kind": "port",
-               "value_per_core": round(v / cores, 1), "cpu_model": model,
+               "value_per_core": round(v / cores, 1), "value_single_core": single["value"] if single else round(v, 1),
+               "single_core_sample_units": single["units"] if single else total, "cpu_model": model,
                "sample": "%d units from the head of the same seeded workload, %d threads, %.1f s wall (%.0f s of CPU work): %s; C "
                          "restatement of zerocaf's u64 backend (oracle/zc_ref.c, gcc -O3), not the Rust binary"
                          % (total, cores, secs, secs * cores, what)}
 
-    metric = {"scalar_mul": "252-bit Edwards variable-base scalar-muls/sec (batched, %s)" % (
-                  "strict bit-exact mode" if args.mode == "strict" else "FAST non-strict mode"),
+    metric = {"scalar_mul": "%d-bit Edwards variable-base scalar-muls/sec (batched, %s)" % (
+                  args.scalar_bits, "strict bit-exact mode" if args.mode == "strict" else "FAST non-strict mode"),
               "msm": "MSM point-scalar pairs/sec (bucket method per GPU, in-library RCCL all-gather + ordered fold across GPUs)",
               "ristretto": "Ristretto decompress -> scalar-mul -> compress round trips/sec (fused, bit-exact encodings)",
               "fe_mul": "FieldElement multiplications/sec (batched, bit-exact canonical limbs)",
@@ -407,7 +562,13 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_spot_check": checked,
+        "devices": idents,
+        "distinct_devices": distinct,
+        "kernel_avg_ms_ranks": {"min": min(d["kernel_avg_ms"] for d in idents), "max": max(d["kernel_avg_ms"] for d in idents)},
     }
+    if wl == "msm":
+        line["rccl_ranks"] = rccl_ranks                      # ncclCommCount of the library's own communicator (None: gloo test hook)
+        line["msm_result_is_fold_of_shard_partials"] = msm_fold_ok
     os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()

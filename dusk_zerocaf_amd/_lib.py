@@ -83,6 +83,7 @@ SIGNATURES = {
     "zc_msm_sharded": [_u64p, _u64p, _n, _u64p],
     "zc_comm_init": [_u8p, C.c_int, C.c_int],
     "zc_comm_destroy": [],
+    "zc_comm_size": [C.POINTER(C.c_int)],
     "zc_ctx_set_stream_dev": [C.c_int, C.c_void_p, C.c_int],
 }
 CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_set_stream", "zc_ctx_synchronize",

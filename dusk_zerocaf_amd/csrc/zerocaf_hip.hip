@@ -79,6 +79,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -746,9 +747,10 @@ int rccl_load()
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
     api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString)
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.CommCount || !api.AllGather || !api.GetErrorString)
         return fail(ZC_ERR_HIP, "librccl.so lacks an expected symbol");
     g_rccl = api;
     return ZC_OK;
@@ -1557,41 +1559,69 @@ int zc_comm_destroy(zc_ctx* ctx)
     return ZC_OK;
 }
 
+// The number of ranks RCCL itself reports for the context's communicator (ncclCommCount); 0 without one.
+// What a scaling record quotes to show that the exchange really ran over N ranks.
+int zc_comm_size(zc_ctx* ctx, int* ranks)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(ranks);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    *ranks = 0;
+    if (ctx->comm) RCCL_TRY(g_rccl.CommCount(ctx->comm, ranks));
+    return ZC_OK;
+}
+
 // BASELINE configs[4]: this rank's shard of a global MSM.  Local bucket method -> ncclAllGather of
 // the 160-byte partial sums over xGMI (20 x ncclUint64 per rank, on the context stream) -> ordered
 // fold in one kernel -> every rank returns the same point (identical limbs).  Point addition is not
 // an ncclRedOp_t, hence all-gather + fold rather than ncclAllReduce.
+// A rank whose local part fails (bad arguments, no memory, a HIP error) still joins the collective -- with a
+// poison record no point can equal (limbs of all ones) -- so that no other rank is left waiting in it; every
+// rank then sees the poison among the gathered rows and ALL of them return an error.
 int zc_msm_sharded(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n_local, uint64_t* out_point)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
     REQUIRE(out_point);
-    if (!ctx->comm) return fail(ZC_ERR_BAD_ARG, "zc_msm_sharded: call zc_comm_init first");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->comm) return fail(ZC_ERR_BAD_ARG, "zc_msm_sharded: call zc_comm_init first");
     DevState* d0 = &ctx->devs[0];
     const size_t world = (size_t)ctx->world;
     HIP_TRY(hipSetDevice(d0->device));
     const size_t front = ctx->devs.size() + 1;               // gather_and_fold's region (multi-slot host inputs)
     int rc = ensure(&d0->part, &d0->part_bytes, (front + world + 2) * 160);
-    if (rc) return rc;
+    if (rc) return rc;                                       // nothing to send from: the one failure that cannot join
     u64* gathered = (u64*)d0->part + 20 * front;
     u64* mine = gathered + 20 * world;                       // mine, then the folded result
+    int local_rc = ZC_OK;
+    std::string local_err;
     if (n_local == 0) {
         HIP_TRY(hipMemcpyAsync(mine, IDENT_POINT, 160, hipMemcpyHostToDevice, d0->s()));
     } else {
-        REQUIRE(points); REQUIRE(scalars);
         DevState* owner = nullptr;
         const u64* res = nullptr;
-        rc = msm_local(ctx, points, scalars, n_local, &owner, &res);
-        if (rc) return rc;
-        if (owner != d0) return fail(ZC_ERR_MIXED_MEM, "zc_msm_sharded: inputs must live on device slot 0 (or on the host)");
+        if (!points || !scalars) local_rc = fail(ZC_ERR_BAD_ARG, "zc_msm_sharded: null points / scalars");
+        if (!local_rc) local_rc = msm_local(ctx, points, scalars, n_local, &owner, &res);
+        if (!local_rc && owner != d0) local_rc = fail(ZC_ERR_MIXED_MEM, "zc_msm_sharded: inputs must live on device slot 0 (or on the host)");
+        if (local_rc) local_err = g_last_error;
         HIP_TRY(hipSetDevice(d0->device));
-        HIP_TRY(hipMemcpyAsync(mine, res, 160, hipMemcpyDeviceToDevice, d0->s()));
+        if (local_rc)
+            HIP_TRY(hipMemsetAsync(mine, 0xFF, 160, d0->s()));
+        else
+            HIP_TRY(hipMemcpyAsync(mine, res, 160, hipMemcpyDeviceToDevice, d0->s()));
     }
     RCCL_TRY(g_rccl.AllGather(mine, gathered, 20, ncclUint64, ctx->comm, d0->s()));
     hipLaunchKernelGGL(zc::k_ed_fold_ordered, dim3(1), dim3(64), 0, d0->s(), (const u64*)gathered, world, (const u64*)nullptr, mine + 20);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_point, mine + 20, 160, hipMemcpyDeviceToHost, d0->s()));
+    std::vector<u64> host(20 * (world + 2));                 // the gathered rows ride along: one small copy
+    HIP_TRY(hipMemcpyAsync(host.data(), gathered, host.size() * sizeof(u64), hipMemcpyDeviceToHost, d0->s()));
     HIP_TRY(hipStreamSynchronize(d0->s()));
+    if (local_rc) {
+        g_last_error = local_err;
+        return local_rc;
+    }
+    for (size_t r = 0; r < world; r++)
+        if (host[20 * r] == ~(u64)0) return fail(ZC_ERR_HIP, ("zc_msm_sharded: rank " + std::to_string(r) + " failed its local part").c_str());
+    memcpy(out_point, host.data() + 20 * (world + 1), 160);
     return ZC_OK;
 }
 

@@ -452,6 +452,12 @@ class Engine:
     def comm_destroy(self):
         self._call("zc_comm_destroy")
 
+    def comm_size(self) -> int:
+        """Ranks of the context's RCCL communicator as RCCL reports them (ncclCommCount); 0 without one."""
+        r = C.c_int(0)
+        self._call("zc_comm_size", C.byref(r))
+        return r.value
+
     def msm_sharded(self, points, scalars):
         """This rank's shard of a global MSM through the library's own RCCL communicator
         (comm_init first): local bucket method, ncclAllGather of the 160-byte partial sums,

@@ -58,6 +58,7 @@ public:
     }
     static void comm_init(const std::array<uint8_t, 128>& id, int rank, int world) { check(zc_comm_init(ctx(), id.data(), rank, world), "zc_comm_init"); }
     static void comm_destroy() { check(zc_comm_destroy(ctx()), "zc_comm_destroy"); }
+    static int comm_size() { int r = 0; check(zc_comm_size(ctx(), &r), "zc_comm_size"); return r; }   // ncclCommCount; 0 without a communicator
 
 private:
     Backend() { check(zc_ctx_create(nullptr, 0, &ctx_), "zc_ctx_create"); }

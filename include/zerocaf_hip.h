@@ -226,15 +226,20 @@ int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t 
  *   zc_comm_*           an RCCL communicator owned by the context (librccl is opened on demand):
  *                       rank 0 calls zc_comm_unique_id, the 128 bytes reach the other ranks by any
  *                       host transport, every rank calls zc_comm_init
+ *   zc_comm_size        the rank count RCCL itself reports for that communicator (ncclCommCount;
+ *                       0 without one): what a scaling record quotes to show N ranks took part
  *   zc_msm_sharded      local bucket method -> ncclAllGather of the 160-byte partials over xGMI ->
  *                       ordered fold -> out_point (HOST memory), identical limbs on every rank.
- *                       (Point addition is not an ncclRedOp_t: all-gather + fold, not all-reduce.) */
+ *                       (Point addition is not an ncclRedOp_t: all-gather + fold, not all-reduce.)
+ *                       A rank whose local part fails still joins the collective (with a poison
+ *                       record) and EVERY rank returns an error: nobody is left waiting.          */
 int zc_msm_partial(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
                    uint64_t *out_dev_point);
 int zc_ed_fold_ordered(zc_ctx *ctx, const uint64_t *parts, size_t count, uint64_t *out);
 int zc_comm_unique_id(uint8_t *id_out128);
 int zc_comm_init(zc_ctx *ctx, const uint8_t *id128, int rank, int world);
 int zc_comm_destroy(zc_ctx *ctx);
+int zc_comm_size(zc_ctx *ctx, int *ranks);
 int zc_msm_sharded(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n_local,
                    uint64_t *out_point);
 

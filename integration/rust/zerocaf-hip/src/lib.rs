@@ -600,6 +600,13 @@ impl HipBackend {
         check(unsafe { ffi::zc_comm_destroy(self.ctx) })
     }
 
+    /// Ranks of the context's RCCL communicator as RCCL reports them (`ncclCommCount`); 0 without one.
+    pub fn comm_size(&self) -> Result<i32> {
+        let mut ranks = 0i32;
+        check(unsafe { ffi::zc_comm_size(self.ctx, &mut ranks) })?;
+        Ok(ranks)
+    }
+
     /// This rank's shard of a global MSM: local bucket method, `ncclAllGather` of the 160-byte
     /// partial sums, ordered fold on the device; every rank gets the same point.
     pub fn msm_sharded(&self, p: &[EdwardsPoint], k: &[Scalar]) -> Result<EdwardsPoint> {

@@ -970,6 +970,54 @@ def test_msm_config5_shard_2_21_vs_oracle(eng, oracle):
     assert eq(oracle.ris_compress(got), oracle.ris_compress(want))
 
 
+@pytest.fixture(scope="module")
+def config5(eng):
+    """BASELINE configs[4] as stated: 2^24 distinct points (r_i * B, fixed-base kernel), S249 scalars, device-resident,
+    and the bucket-method sum over the whole batch."""
+    import torch
+    n = 1 << 24
+    P = eng.ed_mul_base(torch.from_numpy(V.rand_scalars_np(n, V.SEED + 96, bits=249).view(np.int64)).cuda())
+    K = torch.from_numpy(V.rand_scalars_np(n, V.SEED + 97, bits=249).view(np.int64)).cuda()
+    whole = eng.msm(P, K)
+    torch.cuda.synchronize()
+    yield n, P, K, whole
+    del P, K
+    torch.cuda.empty_cache()
+
+
+def test_msm_config5_full_2_24_is_the_ordered_fold_of_its_eight_shards(eng, oracle, config5):
+    """The exact 8-GPU decomposition on one GPU: zc_msm over all 2^24 pairs must be the same group element as
+    zc_ed_fold_ordered of the eight zc_msm_partial results over the contiguous 2^21 ranges, in rank order (the
+    reference's unified addition, edwards.rs:465-489) -- compared with the engine's == and by encodings."""
+    import torch
+    n, P, K, whole = config5
+    per = n // 8
+    parts = torch.cat([eng.msm_partial(P[r * per:(r + 1) * per], K[r * per:(r + 1) * per]) for r in range(8)])
+    folded = eng.ed_fold_ordered(parts)
+    torch.cuda.synchronize()
+    folded = folded.cpu().numpy().view(np.uint64)
+    assert eng.ed_eq(whole, folded)[0] == 1 and oracle.ed_eq(whole, folded)[0] == 1
+    assert eq(eng.ed_compress(whole)[0], eng.ed_compress(folded)[0])
+    assert eq(oracle.ed_compress(whole)[0], oracle.ed_compress(folded)[0])
+    assert eq(oracle.ris_compress(whole), oracle.ris_compress(folded))
+    # the fold itself, limb for limb: the oracle's unified additions over the same eight partials in the same order
+    rows = parts.cpu().numpy().view(np.uint64)
+    acc = rows[0:1].copy()
+    for r in range(1, 8):
+        acc = oracle.ed_add(acc, rows[r:r + 1])
+    assert eq(folded, acc)
+
+
+def test_msm_config5_full_2_24_vs_oracle(eng, oracle, config5):
+    """... and against the oracle's sum of the reference's Mul<Scalar> + Add over ALL 2^24 pairs (about three
+    minutes on 16 host threads): BASELINE configs[4] at its full statement."""
+    n, P, K, whole = config5
+    want = oracle.msm_naive_mt(P.cpu().numpy().view(np.uint64), K.cpu().numpy().view(np.uint64))
+    assert oracle.ed_eq(whole, want)[0] == 1
+    assert eq(oracle.ed_compress(whole)[0], oracle.ed_compress(want)[0])
+    assert eq(oracle.ris_compress(whole), oracle.ris_compress(want))
+
+
 def test_empty_batches_and_in_context_sharding(eng, oracle):
     """n = 0 is a no-op for every call shape; a context over two device slots (the same GPU
     twice here) shards host batches into contiguous ranges and gives identical results."""
