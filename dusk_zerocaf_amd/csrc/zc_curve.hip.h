@@ -479,14 +479,25 @@ ZC_DI pt pt_add(const pt& p, const pt& q)
 // with a factor 1/R (M, P, D directly; C = (dR * T1 / R) * T2 / R), the linear steps keep it, and the four
 // outputs carry 1/R^3 -- one multiplication by R^4 per coordinate returns the plain value.  13 multiplications
 // per addition instead of 8 (into the domain) + 9 + 4 (out of it); the canonical results are the same limbs.
+// A plain coordinate as it comes from memory.  The plain-domain formulas need it R-class (< 3p: fe_sub's subtrahend);
+// canonical limbs are.  Any other 5 x 52-bit pattern (value up to 2^260) is first brought there -- into the Montgomery
+// domain and back, two multiplications -- on a branch canonical data never takes (top limb < 2^44 means value < 2^252),
+// so the kernels answer for the value mod p whatever the limbs, as the Montgomery-domain loads always did.
+ZC_DI fe fe_load_plain(const u64* __restrict__ p)
+{
+    u64 l[5];
+    load5(l, p);
+    fe r = fe_from_limbs52(l);
+    if (l[4] >> 44) r = mont_from<FP>(mont_to<FP>(r));
+    return r;
+}
 ZC_DI pt pt_load_plain(const u64* __restrict__ p)
 {
     pt r;
-    u64 l[5];
-    load5(l, p);      r.X = fe_from_limbs52(l);
-    load5(l, p + 5);  r.Y = fe_from_limbs52(l);
-    load5(l, p + 10); r.Z = fe_from_limbs52(l);
-    load5(l, p + 15); r.T = fe_from_limbs52(l);
+    r.X = fe_load_plain(p);
+    r.Y = fe_load_plain(p + 5);
+    r.Z = fe_load_plain(p + 10);
+    r.T = fe_load_plain(p + 15);
     return r;
 }
 ZC_DI void pt_store_plain_r3(u64* __restrict__ o, const pt& p)           // p = (true value) / R^3 per coordinate

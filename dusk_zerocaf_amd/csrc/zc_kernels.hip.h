@@ -1242,15 +1242,12 @@ ZC_KERNEL void k_proj_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
     const size_t i = gid();
     if (i >= n) return;
     ppt a, b;                                              // plain coordinates: both sides of each comparison carry 1/R
-    {
-        u64 l[5];
-        load5(l, p + 15 * i); a.X = fe_from_limbs52(l);
-        load5(l, p + 15 * i + 5); a.Y = fe_from_limbs52(l);
-        load5(l, p + 15 * i + 10); a.Z = fe_from_limbs52(l);
-        load5(l, q + 15 * i); b.X = fe_from_limbs52(l);
-        load5(l, q + 15 * i + 5); b.Y = fe_from_limbs52(l);
-        load5(l, q + 15 * i + 10); b.Z = fe_from_limbs52(l);
-    }
+    a.X = fe_load_plain(p + 15 * i);
+    a.Y = fe_load_plain(p + 15 * i + 5);
+    a.Z = fe_load_plain(p + 15 * i + 10);
+    b.X = fe_load_plain(q + 15 * i);
+    b.Y = fe_load_plain(q + 15 * i + 5);
+    b.Z = fe_load_plain(q + 15 * i + 10);
     const bool ex = fp_eq(fp_mul(a.X, b.Z), fp_mul(b.X, a.Z));
     const bool ey = fp_eq(fp_mul(a.Y, b.Z), fp_mul(b.Y, a.Z));
     eq[i] = (ex && ey && !fp_is_zero(a.Z) && !fp_is_zero(b.Z)) ? 1 : 0;
@@ -1260,10 +1257,9 @@ ZC_KERNEL void k_proj_is_valid(const u64* p, uint8_t* valid, size_t n)          
     const size_t i = gid();
     if (i >= n) return;
     pt e;                                                  // plain coordinates, as k_ed_is_valid
-    u64 l[5];
-    load5(l, p + 15 * i); e.X = fe_from_limbs52(l);
-    load5(l, p + 15 * i + 5); e.Y = fe_from_limbs52(l);
-    load5(l, p + 15 * i + 10); e.Z = fe_from_limbs52(l);
+    e.X = fe_load_plain(p + 15 * i);
+    e.Y = fe_load_plain(p + 15 * i + 5);
+    e.Z = fe_load_plain(p + 15 * i + 10);
     e.T = fe_zero();
     valid[i] = ed_is_valid(e) ? 1 : 0;
 }

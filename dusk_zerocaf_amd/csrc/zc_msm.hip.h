@@ -112,59 +112,99 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
 // plain inverse of the register value).  A wave whose points all have Z = 1 (decompressed or already affine
 // inputs) skips the inversion.  Z = 0 (no point of the curve) takes the neutral value: garbage in, garbage out.
 constexpr int MSM_AFF_WORDS = 24;
-ZC_DI void msm_prepare_affine_chunk(const u64* __restrict__ p, u32* __restrict__ recs, size_t n, size_t lo, size_t stride, int c)
+// All global traffic of the pass is coalesced: the workgroup's 256 consecutive point records of a step (40 KB) come in
+// through LDS with 16-byte loads (a lane reading its own 160-byte record from global memory issues twenty 8-byte loads on
+// two or three cache lines nobody else in its wave shares), the prefix products go out and come back as one 9 KB block
+// (parked in the records about to be written), and the finished 96-byte records leave through the same LDS buffer.
+ZC_DI void coop_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, int nvec)
 {
-    const size_t avail = lo < n ? (n - lo + stride - 1) / stride : 0;
-    const int cnt = (int)(avail < (size_t)c ? avail : (size_t)c);
+    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) dst[v] = src[v];
+}
+ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c)
+{
+    __shared__ __attribute__((aligned(16))) u64 sp[ZC_BLOCK * 20];          // 256 point records in, 256 affine records out
+    __shared__ __attribute__((aligned(16))) u32 spre[ZC_BLOCK * 9];         // 256 prefix products
+    const int t = threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * ZC_BLOCK;                      // lane g owns points g, g + stride, g + 2 stride, ...
+    const size_t first = (size_t)blockIdx.x * ZC_BLOCK;
     const fe neutral = fe_one_m<FP>();
     fe acc = neutral;
     bool all_one = true;
-    for (int j = 0; j < cnt; j++) {
-        const size_t i = lo + (size_t)j * stride;
-        u64 l[5];
-        load5(l, p + 20 * i + 10);
-        all_one = all_one && l[0] == 1 && (l[1] | l[2] | l[3] | l[4]) == 0;
-        const fe z = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
-        u32* slot = recs + MSM_AFF_WORDS * i;
+    int steps = 0;                                                           // steps of this workgroup (the same for all its lanes)
+    for (int j = 0; j < c; j++) {
+        const size_t base = first + (size_t)j * stride;
+        if (base >= n) break;
+        steps = j + 1;
+        const int cnt = (int)(n - base < (size_t)ZC_BLOCK ? n - base : (size_t)ZC_BLOCK);
+        __syncthreads();
+        coop_load40<false>(sp, points + 20 * base, cnt * 4);
+        __syncthreads();
+        if (t < cnt) {
+            u64 l[5];
+            load5(l, sp + 20 * t + 10);
+            all_one = all_one && l[0] == 1 && (l[1] | l[2] | l[3] | l[4]) == 0;
+            const fe z = fe_select(limbs52_all_zero(l), neutral, fe_from_limbs52(l));
 #pragma unroll
-        for (int w = 0; w < 9; w++) slot[w] = acc.v[w];
-        acc = fp_mul(acc, z);
-    }
-    const bool skip = __all(all_one) != 0;                  // wave-uniform
-    fe inv = neutral;
-    if (!skip) inv = fp_inverse_of_register(acc);
-    const fe d2 = fe_const<FP>(ModP::D2_M);
-    for (int j = cnt - 1; j >= 0; j--) {
-        const size_t i = lo + (size_t)j * stride;
-        u64 lx[5], ly[5], lz[5], lt[5];
-        load5(lx, p + 20 * i);
-        load5(ly, p + 20 * i + 5);
-        load5(lz, p + 20 * i + 10);
-        load5(lt, p + 20 * i + 15);
-        u32* slot = recs + MSM_AFF_WORDS * i;
-        fe zi2 = fe_const<FP>(ModP::RR);                        // (1 / Z) R^2
-        if (!skip) {
-            const fe z = fe_select(limbs52_all_zero(lz), neutral, fe_from_limbs52(lz));
-            fe pre;
-#pragma unroll
-            for (int w = 0; w < 9; w++) pre.v[w] = slot[w];
-            zi2 = fp_mul(fp_mul(inv, pre), fe_const<FP>(ModP::R3));
-            inv = fp_mul(inv, z);
+            for (int w = 0; w < 9; w++) spre[9 * t + w] = acc.v[w];
+            acc = fp_mul(acc, z);
         }
-        const fe xm = fp_mul(fe_from_limbs52(lx), zi2);         // x R
-        const fe ym = fp_mul(fe_from_limbs52(ly), zi2);         // y R
-        const fe tm = fp_mul(fe_from_limbs52(lt), zi2);         // (T / Z) R = x y R
-        fe ypx = fe_add(ym, xm);
-        fe_carry(ypx);
-        pack256(slot, fp_sub(ym, xm));                          // normalized, < 7N < 2^256
-        pack256(slot + 8, ypx);
-        pack256(slot + 16, fp_mul(tm, d2));
+        __syncthreads();
+        // the step's prefix products wait in the first 9 KB of the 24 KB the step's records will occupy (whole 16-byte
+        // vectors: the tail of a partial block may run a few words into the next lane-less slots of the same region)
+        coop_copy16(reinterpret_cast<uint4*>(recs + MSM_AFF_WORDS * base), reinterpret_cast<const uint4*>(spre), (cnt * 9 + 3) / 4);
     }
-}
-ZC_KERNEL void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c)
-{
-    const size_t lanes = ((n + (size_t)c - 1) / (size_t)c + 63) & ~(size_t)63, g = gid();      // whole waves: the skip vote is wave-wide
-    if (g < lanes) msm_prepare_affine_chunk(points, recs, n, g, lanes, c);
+    // one inversion per lane (the lanes of a wave run it in lock step: it is shared by the lane's own points, not across lanes);
+    // a workgroup whose points all have Z = 1 needs none
+    __shared__ int s_any;
+    if (t == 0) s_any = 0;
+    __syncthreads();
+    if (!all_one) s_any = 1;
+    __syncthreads();
+    const bool skip = s_any == 0;
+    fe inv = neutral;
+    if (!skip) inv = fp_inverse_of_register(acc) , inv = fp_mul(inv, fe_const<FP>(ModP::R3));   // carries R^3 from here on: inv * pre = R^2 / Z
+    const fe d2 = fe_const<FP>(ModP::D2_M);
+    for (int j = steps - 1; j >= 0; j--) {
+        const size_t base = first + (size_t)j * stride;
+        const int cnt = (int)(n - base < (size_t)ZC_BLOCK ? n - base : (size_t)ZC_BLOCK);
+        __syncthreads();
+        coop_load40<false>(sp, points + 20 * base, cnt * 4);
+        if (!skip) coop_copy16(reinterpret_cast<uint4*>(spre), reinterpret_cast<const uint4*>(recs + MSM_AFF_WORDS * base), (cnt * 9 + 3) / 4);
+        __syncthreads();
+        fe ymx, ypx, t2d;
+        if (t < cnt) {
+            u64 lx[5], ly[5], lz[5], lt[5];
+            load5(lx, sp + 20 * t);
+            load5(ly, sp + 20 * t + 5);
+            load5(lz, sp + 20 * t + 10);
+            load5(lt, sp + 20 * t + 15);
+            fe zi2 = fe_const<FP>(ModP::RR);                    // (1 / Z) R^2
+            if (!skip) {
+                const fe z = fe_select(limbs52_all_zero(lz), neutral, fe_from_limbs52(lz));
+                fe pre;
+#pragma unroll
+                for (int w = 0; w < 9; w++) pre.v[w] = spre[9 * t + w];
+                zi2 = fp_mul(inv, pre);
+                inv = fp_mul(inv, z);
+            }
+            const fe xm = fp_mul(fe_from_limbs52(lx), zi2);     // x R
+            const fe ym = fp_mul(fe_from_limbs52(ly), zi2);     // y R
+            const fe tm = fp_mul(fe_from_limbs52(lt), zi2);     // (T / Z) R = x y R
+            ypx = fe_add(ym, xm);
+            fe_carry(ypx);
+            ymx = fp_sub(ym, xm);                               // normalized, < 7N < 2^256
+            t2d = fp_mul(tm, d2);
+        }
+        __syncthreads();                                        // every lane has read its point: the buffer takes the records
+        if (t < cnt) {
+            u32* o = reinterpret_cast<u32*>(sp) + MSM_AFF_WORDS * t;
+            pack256(o, ymx);
+            pack256(o + 8, ypx);
+            pack256(o + 16, t2d);
+        }
+        __syncthreads();
+        coop_copy16(reinterpret_cast<uint4*>(recs + MSM_AFF_WORDS * base), reinterpret_cast<const uint4*>(sp), cnt * 6);
+    }
 }
 // Bucket sums are kept in the kernels' own number system between k_msm_runs and k_msm_segments:
 // 36 x u32 (X, Y, Z, T as nine 29-bit Montgomery limbs each, R-class), 144 bytes per bucket.  A

@@ -70,6 +70,9 @@ struct DevState {
     void* part = nullptr;               // MSM exchange: gathered per-rank / per-device partials + the folded result
     size_t part_bytes = 0;
     hipEvent_t ev_order = nullptr;      // orders work across a stream switch / across devices
+    hipStream_t aux = nullptr;          // MSM: the point normalisation runs beside the key sort (other priority than `stream`:
+                                        // two streams of one priority share a hardware queue here and run one after the other)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -615,7 +618,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     const int seg = zc::msm_segment_buckets(nb);
     const size_t nseg = nb / (size_t)seg;
     const MsmSortPlan plan = msm_sort_plan(cnt, c, W);
-    const bool affine = msm_affine(cnt);
+    const bool affine = msm_affine(cnt) && aligned16(dP);   // the normalisation moves the point records with 16-byte loads
 
     // run length of the segmented reduction: 128 entries per lane, fewer when the list is short (keep
     // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
@@ -653,11 +656,14 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             if (rc) return rc;
             continue;
         }
-        hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, digits, cnt, c, W);
-        const uint2* sorted = nullptr;
-        {
-            int rc = msm_sort(D, plan, digits, pairs_a, pairs_b, sort_table, sort_sums, &sorted);
-            if (rc) return rc;
+        // the point normalisation (an inversion-heavy, half compute-bound pass) runs on a second stream beside the key
+        // sort (latency- and bandwidth-bound): they share no buffer, and the bucket sums wait for both.  ZC_MSM_FORK=0: in line.
+        static const bool fork = [] { const char* e = getenv("ZC_MSM_FORK"); return !(e && atoi(e) == 0); }();
+        hipStream_t ps = D.s();
+        if (fork && D.aux) {
+            HIP_TRY(hipEventRecord(D.ev_fork, D.s()));
+            HIP_TRY(hipStreamWaitEvent(D.aux, D.ev_fork, 0));
+            ps = D.aux;
         }
         if (affine) {
             // points per lane of the normalisation: enough lanes for two to four waves per SIMD, enough points per
@@ -667,11 +673,19 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 const int f = atoi(e);
                 if (f >= 1 && f <= 64) ac = f;
             }
-            const size_t lanes = ((cnt + ac - 1) / ac + 63) & ~(size_t)63;
-            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt, ac);
+            const size_t lanes = (cnt + ac - 1) / ac;            // lane g owns points g, g + stride, ...: stride = the launch's lanes
+            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt, ac);
         } else {
-            hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, cached, cnt);
+            hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt);
         }
+        if (ps != D.s()) HIP_TRY(hipEventRecord(D.ev_join, ps));
+        hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, digits, cnt, c, W);
+        const uint2* sorted = nullptr;
+        {
+            int rc = msm_sort(D, plan, digits, pairs_a, pairs_b, sort_table, sort_sums, &sorted);
+            if (rc) return rc;
+        }
+        if (ps != D.s()) HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_join, 0));
         HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
         // bucket sums: segmented reduction of the sorted list in runs of T, level by level
         {
@@ -844,6 +858,13 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_in, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.copy_out, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_order, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);         // lowest, highest (numerically smaller = higher)
+            e = hipStreamCreateWithPriority(&ds.aux, hipStreamNonBlocking, lo_p);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming);
         if (e != hipSuccess) {
             delete ctx;
             return fail(ZC_ERR_HIP, "stream creation", e);
@@ -864,6 +885,9 @@ int zc_ctx_destroy(zc_ctx* ctx)
         (void)hipStreamSynchronize(ds.s());
         if (ds.part) (void)hipFree(ds.part);
         if (ds.ev_order) (void)hipEventDestroy(ds.ev_order);
+        if (ds.ev_fork) (void)hipEventDestroy(ds.ev_fork);
+        if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
+        if (ds.aux) (void)hipStreamDestroy(ds.aux);
         for (int a = 0; a < MAX_ARGS; a++)
             if (ds.scratch[a]) (void)hipFree(ds.scratch[a]);
         for (int a = 0; a < 2; a++)

@@ -32,7 +32,8 @@ class Engine:
         self.lib = _lib.load()
         self.ctx = C.c_void_p()
         self._pinned_stream = False      # set_stream() was called: keep that stream
-        self._last_torch_stream = None
+        self._last_torch_stream = {}     # device slot -> handle of the torch stream last bound to it
+        self._devices = list(devices) if devices else None      # slot i of the context = HIP device _devices[i]
         if devices:
             arr = (C.c_int * len(devices))(*devices)
             rc = self.lib.zc_ctx_create(arr, len(devices), C.byref(self.ctx))
@@ -60,23 +61,32 @@ class Engine:
     def use_own_stream(self):
         """Back to the default: host batches run on the context's own stream; calls on torch CUDA
         tensors follow torch's current stream of that device (see _follow_torch_stream)."""
-        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, None, 0), "zc_ctx_set_stream")
+        for slot in (range(len(self._devices)) if self._devices else (0,)):
+            _lib.check(self.lib.zc_ctx_set_stream_dev(self.ctx, slot, None, 0), "zc_ctx_set_stream_dev")
         self._pinned_stream = False
-        self._last_torch_stream = None
+        self._last_torch_stream = {}
 
     def _follow_torch_stream(self, t):
         """Device tensors are produced and consumed on torch's streams and their memory belongs to
         torch's caching allocator, so unless the caller pinned a stream with set_stream() every
         call on torch tensors is enqueued on torch.cuda.current_stream(device): ordered after the
         work that produced the inputs, and outputs allocated with torch.empty are safe to use from
-        that stream.  (The library orders a stream switch with an event, no host sync.)"""
+        that stream.  (The library orders a stream switch with an event, no host sync.)
+        The stream is bound to the context slot that OWNS the tensor's device (a multi-device engine keeps
+        one stream per slot); a tensor on a device outside the context is refused here, before any launch."""
         if self._pinned_stream:
             return
         import torch
+        slot = 0
+        if self._devices is not None:
+            dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+            if dev not in self._devices:
+                raise _lib.ZerocafHipError("tensor on cuda:%d, but this engine's context owns devices %s" % (dev, self._devices))
+            slot = self._devices.index(dev)
         h = torch.cuda.current_stream(t.device).cuda_stream
-        if h != self._last_torch_stream:
-            _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(h), 1), "zc_ctx_set_stream")
-            self._last_torch_stream = h
+        if self._last_torch_stream.get(slot) != h:
+            _lib.check(self.lib.zc_ctx_set_stream_dev(self.ctx, slot, C.c_void_p(h), 1), "zc_ctx_set_stream_dev")
+            self._last_torch_stream[slot] = h
 
     def synchronize(self):
         _lib.check(self.lib.zc_ctx_synchronize(self.ctx), "zc_ctx_synchronize")

@@ -104,3 +104,32 @@ int main(void) {
                            "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True)
     assert out.startswith("zerocaf_hip") and out.strip().endswith("|1|1")
+
+
+def test_engine_binds_torch_streams_to_the_slot_that_owns_the_tensor():
+    """A multi-device Engine keeps one stream per context slot: following torch's current stream must bind it to the
+    slot of the TENSOR's device (zc_ctx_set_stream_dev), and a tensor on a device outside the context is refused
+    before anything is launched.  (No GPU needed: the library call is recorded, not made.)"""
+    import types
+    import dusk_zerocaf_amd as z
+    from dusk_zerocaf_amd.engine import Engine
+    calls = []
+    e = Engine.__new__(Engine)
+    e.ctx, e._pinned_stream, e._last_torch_stream, e._devices = None, False, {}, [2, 5]
+    e.lib = types.SimpleNamespace(zc_ctx_set_stream_dev=lambda ctx, slot, h, ext: calls.append((slot, h.value, ext)) or 0)
+    import torch
+    handle = {2: 0x1000, 5: 0x2000}
+    orig = torch.cuda.current_stream
+    torch.cuda.current_stream = lambda dev=None: types.SimpleNamespace(cuda_stream=handle[dev.index])
+    try:
+        t2 = types.SimpleNamespace(device=types.SimpleNamespace(index=2))
+        t5 = types.SimpleNamespace(device=types.SimpleNamespace(index=5))
+        e._follow_torch_stream(t5)
+        e._follow_torch_stream(t2)
+        e._follow_torch_stream(t5)                           # cached per slot: no second call
+        assert calls == [(1, 0x2000, 1), (0, 0x1000, 1)]
+        with pytest.raises(z.ZerocafHipError):
+            e._follow_torch_stream(types.SimpleNamespace(device=types.SimpleNamespace(index=3)))
+    finally:
+        torch.cuda.current_stream = orig
+        e.ctx = None

@@ -397,6 +397,38 @@ def test_extreme_operands(eng, oracle):
     assert eq(eng.proj_add(A3, B3), oracle.proj_add(A3, B3)) and eq(eng.proj_double(A3), oracle.proj_double(A3))
 
 
+def test_noncanonical_limbs_answer_for_the_value_mod_p(eng, oracle):
+    """The stand-alone point kernels and the predicates (==, is_valid) work on plain coordinates; they must answer
+    for the value mod p whatever 5 x 52-bit pattern carries it (untrusted data reaches == and is_valid): each
+    coordinate as v, v + p, v + 37 p and v + k p just below 2^260 gives the results of the canonical limbs."""
+    n = 64
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 320, bits=249))
+    Q = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 321, bits=249))
+    rng = np.random.default_rng(V.SEED + 322)
+
+    def lift(A, width):
+        out = A.copy()
+        for i in range(len(A)):
+            for cidx in range(width // 5):
+                v = sum(int(A[i, 5 * cidx + j]) << (52 * j) for j in range(5))
+                k = [0, 1, 37, ((1 << 260) - 1 - v) // pm.P][int(rng.integers(0, 4))]
+                out[i, 5 * cidx:5 * cidx + 5] = pm.limbs(v + k * pm.P)
+        return out
+
+    P2, Q2 = lift(P, 20), lift(Q, 20)
+    assert not eq(P, P2)
+    assert eq(eng.ed_add(P2, Q2), eng.ed_add(P, Q)) and eq(eng.ed_sub(P2, Q2), eng.ed_sub(P, Q))
+    assert eq(eng.ed_double(P2), eng.ed_double(P)) and eq(eng.ed_coset4(P2)[:, 20:], eng.ed_coset4(P)[:, 20:])
+    assert eng.ed_eq(P2, P).tolist() == [1] * n and eng.ed_eq(P2, Q).tolist() == [0] * n
+    assert eng.ris_eq(P2, P).tolist() == [1] * n
+    assert eng.ed_is_valid(P2).tolist() == [1] * n
+    bad = P2.copy()
+    bad[:, 0] ^= np.uint64(1)                                     # off the curve
+    assert eng.ed_is_valid(bad).tolist() == [0] * n
+    A3, B3 = np.ascontiguousarray(P[:, :15]), np.ascontiguousarray(P2[:, :15])
+    assert eng.proj_eq(A3, B3).tolist() == [1] * n and eng.proj_is_valid(B3).tolist() == [1] * n
+
+
 def _edge_scalars(K):
     K[0] = 0
     if len(K) > 8:
@@ -765,6 +797,41 @@ def test_fixed_base_key_generation(eng, oracle):
     s12, ok1 = eng.ris_roundtrip_mul(pkb, K2)
     s21, ok2 = eng.ris_roundtrip_mul(eng.ris_mul_base_compress(K2), Kb)
     assert ok1.all() and ok2.all() and eq(s12, s21)
+
+
+def test_reference_odd_multiples_table_and_window_naf_mul_on_the_gpu(eng, oracle, kats):
+    """N1, literally: the reference's BASEPOINT_ODD_MULTIPLES_TABLE (constants.rs:216-972: 125 affine KATs for
+    (2j-1) B) against zc_ed_mul_base, and the CORRECT window_naf_mul (edwards.rs:155-171 mis-indexes the table)
+    assembled from kernels that exist: zc_sc_compute_naf(k, w) digits, that table, zc_ed_double / add / sub --
+    it must reproduce k B for every width w = 2 .. 7."""
+    table = np.array([sum(p, []) for p in kats["odd_multiples_table"]["points"]], dtype=np.uint64)
+    assert table.shape == (126, 20)
+    odd = np.zeros((125, 5), dtype=np.uint64)
+    odd[:, 0] = np.arange(1, 250, 2)
+    assert eng.ed_eq(eng.ed_mul_base(odd), table[1:]).tolist() == [1] * 125
+    assert eng.ed_eq(eng.ed_scalar_mul(np.tile(table[1:2], (125, 1)), odd), table[1:]).tolist() == [1] * 125
+    K = V.rand_scalars_np(12, V.SEED + 310, bits=249)
+    K[0] = 0
+    K[1] = [1, 0, 0, 0, 0]
+    K[2] = V.limbs_array([pm.L - 1])[0]
+    kv = [sum(int(K[i, j]) << (52 * j) for j in range(5)) for i in range(len(K))]
+    want = eng.ed_mul_base(K)
+    base = np.tile(table[1:2], (len(K), 1))
+    assert eng.ed_eq(want, oracle.ed_scalar_mul(base, K)).tolist() == [1] * len(K)
+    for w in range(2, 8):
+        naf = np.asarray(eng.sc_compute_naf(K, w)).astype(np.int64)
+        assert [sum(int(d) << i for i, d in enumerate(row)) for row in naf] == kv                 # digit i weighs 2^i
+        assert np.all((naf == 0) | ((naf % 2 != 0) & (np.abs(naf) < (1 << (w - 1)))))          # odd, |d| < 2^(w-1)
+        acc = np.tile(np.array([V.IDENT_ROW], dtype=np.uint64), (len(K), 1))
+        for i in range(255, -1, -1):
+            acc = eng.ed_double(acc)
+            d = naf[:, i]
+            if not d.any():
+                continue
+            entry = table[(np.abs(d) + 1) // 2 * (d != 0)]                                        # entry j = (2j - 1) B, entry 0 = identity
+            acc = np.where((d < 0)[:, None], eng.ed_sub(acc, entry), eng.ed_add(acc, entry))
+        assert eng.ed_eq(acc, want).tolist() == [1] * len(K), w
+        assert eq(eng.ed_compress(acc)[0], eng.ed_compress(want)[0]), w
 
 
 def test_fixed_base_comb_digit_edges(eng, oracle):
