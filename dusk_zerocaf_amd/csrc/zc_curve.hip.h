@@ -943,8 +943,19 @@ ZC_DI pt fast_window_loop(const TABLE table, const int8_t* __restrict__ dig, int
         const int d = dig[i * stride];
         const int mag = d < 0 ? -d : d;
         niels c = niels_identity();
+#ifdef ZC_FAST_PROBE_AFFINE    // timing probe only (wrong results): what affine table entries would save in this loop -- 96 bytes per
+                               // entry and the 7-multiplication addition -- WITHOUT the normalisation that would have to pay for it
+        if (mag != 0) {
+            const uint4* v = reinterpret_cast<const uint4*>(table.entry(mag - 1));
+            c.ymx = unpack256(v[0], v[1]);
+            c.ypx = unpack256(v[2], v[3]);
+            c.t2d = unpack256(v[4], v[5]);
+        }
+        Q = pt_add_cached<ILP, true>(Q, niels_cond_neg(d < 0, c));
+#else
         if (mag != 0) c = niels_load(table.entry(mag - 1));
         Q = pt_add_cached<ILP>(Q, niels_cond_neg(d < 0, c));
+#endif
     }
     return Q;
 }

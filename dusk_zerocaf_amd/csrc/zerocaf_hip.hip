@@ -481,7 +481,7 @@ int msm_window_bits(size_t cnt)
     c -= 4;
     if (c == 15 || c == 16) c = 17;                       // 2^19, 2^20 pairs: 16 windows of 17 bits beat 18 of 15 / 17 of 16 (measured -4 %)
     if (c < zc::MSM_MIN_C) c = zc::MSM_MIN_C;
-    if (c > 19) c = 19;                                   // beyond: flat in time (measured to 2^24), bucket memory doubles per step
+    if (c > 18) c = 18;                                   // beyond: no faster (2^24 pairs: c = 18 / 19 / 20: 21.4 / 21.9 / 22.9 ms), bucket memory doubles per step
     if (const char* e = getenv("ZC_MSM_WINDOW")) {
         const int f = atoi(e);
         if (f >= zc::MSM_MIN_C && f <= zc::MSM_MAX_C) c = f;
