@@ -624,7 +624,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
     // levels.  Measured (tools/quick_bench.py, ZC_MSM_RUN / ZC_MSM_RUN_EDGES): 2^20 pairs T = 32 / 128 / 256:
     // 2.90 / 2.83 / 3.12 ms; 2^21: 4.67 / 4.48 / 4.52; edge runs of 8 / 16 / 32: 2^21 4.44 / 4.53 / 4.63 ms.
-    int T = (int)std::min<size_t>(128, std::max<size_t>(8, m >> 17));
+    // Round 3, 2^24 pairs (2^27.9 entries): T = 128 / 256: 21.94 / 21.53 ms -- half the edges for the deeper levels.
+    int T = m >= ((size_t)1 << 27) ? 256 : (int)std::min<size_t>(128, std::max<size_t>(8, m >> 17));
     int TE = 8;                                           // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
     if (const char* e = getenv("ZC_MSM_RUN")) {
         const int f = atoi(e);
@@ -657,8 +658,12 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             continue;
         }
         // the point normalisation (an inversion-heavy, half compute-bound pass) runs on a second stream beside the key
-        // sort (latency- and bandwidth-bound): they share no buffer, and the bucket sums wait for both.  ZC_MSM_FORK=0: in line.
-        static const bool fork = [] { const char* e = getenv("ZC_MSM_FORK"); return !(e && atoi(e) == 0); }();
+        // sort (latency- and bandwidth-bound): they share no buffer, and the bucket sums wait for both.  Measured, 2^21 pairs:
+        // 3.89 -> 3.80 ms (the sort's kernels slow down beside it, the pair still ends 60-90 us earlier); at 2^24 both sides are
+        // bandwidth-bound for milliseconds and the pair ends no earlier (21.5 vs 21.7 ms), so large shards stay in line.
+        // ZC_MSM_FORK=0/1 forces the choice.
+        static const int fork_env = [] { const char* e = getenv("ZC_MSM_FORK"); return e ? atoi(e) : -1; }();
+        const bool fork = fork_env >= 0 ? fork_env != 0 : cnt < ((size_t)1 << 23);
         hipStream_t ps = D.s();
         if (fork && D.aux) {
             HIP_TRY(hipEventRecord(D.ev_fork, D.s()));

@@ -27,8 +27,11 @@ WORKLOADS = {
     # name: (units per call, algorithmic bytes per unit, dispatch filter, ISA-mix kernel)
     "scalar_mul": (1 << 20, 360, lambda k: k.startswith(("k_ed_scalar_mul", "k_sm_cost")), "k_ed_scalar_mul_pw"),
     "ristretto": (1 << 22, 104, lambda k: k.startswith("k_ris_roundtrip_mul_fast"), "k_ris_roundtrip_mul_fast"),
-    "msm": (1 << 21, 200, lambda k: not k.startswith(("k_ed_mul_base", "k_base_table_build", "k_mad_chains")), "k_msm_runs"),   # not the inputs, not the live rate measurement
+    # the MSM's own kernels only: not the inputs (k_ed_mul_base, k_base_table_build), not the live rate measurement
+    # (k_mad_chains), not the runtime's fill / copy kernels, which multiply nothing
+    "msm": (1 << 21, 200, lambda k: k.startswith(("k_msm", "k_scan", "k_ed_scalar_mul", "k_ed_add", "k_ed_fold")), "k_msm_runs_affine"),
 }
+MSM_STEP_KERNELS = ("k_msm", "k_scan", "k_ed_scalar_mul", "k_ed_add", "k_ed_fold")
 
 
 def totals(path, keep):
@@ -60,6 +63,7 @@ def parse_occupancy(path):
 
 def main():
     pmc_dir, occ_path, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    prof_dir = sys.argv[4] if len(sys.argv) > 4 else None      # gpurun_out/prof_<tag>: kernel traces (the MSM's k_msm_runs share)
     prof = os.path.join(ROOT, "profiles")
     raw = os.path.join(prof, tag + "_raw")
     os.makedirs(raw, exist_ok=True)
@@ -121,7 +125,17 @@ def main():
              "isa_mix_kernel": mixk,
              "hbm_read_bytes_per_unit": rd, "hbm_write_bytes_per_unit": wr,
              "hbm_bytes_per_unit": (rd + wr) if rd is not None and wr is not None else None,
-             "algorithmic_bytes_per_unit": alg}
+             "algorithmic_bytes_per_unit": alg, "kernels_counted": sorted(per_kernel)}
+        if wl == "msm" and prof_dir:
+            st = os.path.join(prof_dir, "kt_msm_2p21_kernel_stats.csv")
+            if os.path.exists(st):
+                rows = [r for r in csv.DictReader(open(st)) if r["Name"].startswith(MSM_STEP_KERNELS)]
+                tot = sum(float(r["TotalDurationNs"]) for r in rows)
+                runs = [r for r in rows if r["Name"].startswith("k_msm_runs_affine")]
+                if runs and tot:
+                    k["runs_time_share"] = round(float(runs[0]["TotalDurationNs"]) / tot, 4)
+                    k["runs_avg_ms"] = round(float(runs[0]["AverageNs"]) / 1e6, 4)
+                    k["runs_source"] = "profiles/%s_raw/kt_msm_2p21_kernel_stats.csv (share of the summed kernel time of a step)" % tag
         for name in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                      "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
                      "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
@@ -149,9 +163,15 @@ def main():
             md.append("| resident waves per busy SQ cycle | %.2f | SQ_WAVE_CYCLES / SQ_BUSY_CYCLES |" % (c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"]))
         md.append("")
         if len(per_kernel) > 1:
-            md += ["| kernel | SQ_INSTS_VALU per call | FETCH_SIZE KiB per call | WRITE_SIZE KiB per call |", "|---|---|---|---|"]
+            md += ["| kernel | SQ_INSTS_VALU per call | 2 x FETCH_SIZE MB per call | WRITE_SIZE MB per call | LDS bank-conflict / LDS active cycles | wave cycles issuing / issue-stalled / parked |",
+                   "|---|---|---|---|---|---|"]
             for kn, v in sorted(per_kernel.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
-                md.append("| %s | %.3e | %.0f | %.0f |" % (kn, v.get("SQ_INSTS_VALU", 0) / CALLS, v.get("FETCH_SIZE", 0) / CALLS, v.get("WRITE_SIZE", 0) / CALLS))
+                conf = "%.3f (%.2e / %.2e)" % (v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], v["SQ_LDS_BANK_CONFLICT"] / CALLS, v["SQ_LDS_IDX_ACTIVE"] / CALLS) \
+                    if v.get("SQ_LDS_IDX_ACTIVE") else "no LDS"
+                wcy = v.get("SQ_WAVE_CYCLES")
+                split = " / ".join("%.2f" % (v.get(n, 0) / wcy) for n in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")) if wcy else ""
+                md.append("| %s | %.3e | %.1f | %.1f | %s | %s |" % (kn, v.get("SQ_INSTS_VALU", 0) / CALLS, 2 * v.get("FETCH_SIZE", 0) / CALLS / 1024,
+                                                                v.get("WRITE_SIZE", 0) / CALLS / 1024, conf, split))
             md.append("")
     md += ["## Instruction rates behind `roofline.peak` (profiles/%s_ubench_occupancy.txt)" % tag, "",
            "```", json.dumps(ubench, indent=1), "```", ""]

@@ -4,11 +4,11 @@
 #                                        gpurun_out/pmc_<tag>/  (PMC passes, tools/profile_pmc.sh)
 # then, back in the container:
 #   python tools/summarize_profiles.py gpurun_out/prof_<tag> <tag>
-#   python tools/make_roofline_inputs.py gpurun_out/pmc_<tag> gpurun_out/prof_<tag>/occupancy.txt <tag>
+#   python tools/make_roofline_inputs.py gpurun_out/pmc_<tag> gpurun_out/prof_<tag>/occupancy.txt <tag> gpurun_out/prof_<tag>
 # rocprofv3 passes: kernel trace + stats per workload; PMC counters in their own passes (no trace
 # domains), as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 MODE=${2:-all}            # "bench": only the bench.py lines (after profiles/roofline_inputs.json was regenerated)
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -41,6 +41,7 @@ python bench.py --workload ristretto --units 4194304 --steps 3 --warmup 1 > "$OU
 python bench.py --workload fe_mul > "$OUT/bench_fe_mul_2p20.json" 2>/dev/null
 python bench.py --workload fe_mul --units 16777216 --steps 20 --warmup 30 --cpu-sample 0 > "$OUT/bench_fe_mul_2p24.json" 2>/dev/null
 python bench.py --workload fe_invert > "$OUT/bench_fe_invert_2p20.json" 2>/dev/null
+python bench.py --workload fe_invert --units 16777216 --steps 10 --warmup 5 --cpu-sample 65536 > "$OUT/bench_fe_invert_2p24.json" 2>/dev/null
 python bench.py --workload msm > "$OUT/bench_msm_2p20.json" 2>/dev/null
 python bench.py --workload msm --units 2097152 > "$OUT/bench_msm_2p21.json" 2>/dev/null
 python bench.py --workload msm --units 16777216 --steps 3 --warmup 1 > "$OUT/bench_msm_2p24.json" 2>/dev/null
