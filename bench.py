@@ -512,7 +512,7 @@ def main():
         single = None
         if baseline_leg and cores > 1:
             # the measured one-thread leg: the same operation on 1 / cores of the sample, one host thread
-            m1 = max(1, total // cores)
+            m1 = min(n, max(1, total // cores))
             host1 = lambda t: np.ascontiguousarray(t[:m1].cpu().numpy()).view(np.uint64)
             t1 = time.perf_counter()
             if wl == "fe_mul":
