@@ -449,14 +449,18 @@ def main():
             rec = 96 if n >= (1 << 17) else 128
             g = {"record_bytes": rec, "records": basis["nonzero_digits_per_pair"] * n, "unit": "GB/s", "peak": HBM_COPY_GBS,
                  "peak_basis": "what a device copy reaches (MI355X_MICROARCH.md); random %d-byte gathers" % rec}
-            share = kin.get("runs_time_share")
-            if share:
-                g["achieved"] = round(rec * digits / (kern_avg_s * share) / 1e9, 1)
+            runs = (kin.get("runs") or {}).get(str(n))
+            if runs:
+                # the bucket-sum kernel alone (its average duration in this build's kernel trace): gathered bytes against the
+                # copy rate, and its multiplications against the multiplier roof -- the higher fraction names the bound
+                t_runs = runs["avg_ms"] * 1e-3
+                g["achieved"] = round(rec * digits / t_runs / 1e9, 1)
                 g["frac"] = round(g["achieved"] / HBM_COPY_GBS, 4)
-                g["runs_time_share"] = share
-                g["source"] = inp.get("source")
-                if roofline["frac"] is not None and g["frac"] > roofline["frac"]:
-                    roofline["bound"] = "gather"
+                g["k_msm_runs_avg_ms"] = runs["avg_ms"]
+                g["k_msm_runs_time_share"] = runs["time_share"]
+                g["k_msm_runs_multiplier_frac"] = round(useful / t_runs / 1e12 / peak, 4)
+                g["source"] = runs["source"]
+                roofline["bound"] = "gather" if g["frac"] > g["k_msm_runs_multiplier_frac"] else "valu_int_mul"
             roofline["gather"] = g
         if stale:
             roofline["profile_note"] = stale

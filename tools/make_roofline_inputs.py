@@ -127,15 +127,18 @@ def main():
              "hbm_bytes_per_unit": (rd + wr) if rd is not None and wr is not None else None,
              "algorithmic_bytes_per_unit": alg, "kernels_counted": sorted(per_kernel)}
         if wl == "msm" and prof_dir:
-            st = os.path.join(prof_dir, "kt_msm_2p21_kernel_stats.csv")
-            if os.path.exists(st):
+            # the bucket-sum kernel's share of a step, per traced size (the gather block of bench.py prices that kernel alone)
+            k["runs"] = {}
+            for units_tag, units_n in (("2p21", 1 << 21), ("2p24", 1 << 24)):
+                st = os.path.join(prof_dir, "kt_msm_%s_kernel_stats.csv" % units_tag)
+                if not os.path.exists(st):
+                    continue
                 rows = [r for r in csv.DictReader(open(st)) if r["Name"].startswith(MSM_STEP_KERNELS)]
                 tot = sum(float(r["TotalDurationNs"]) for r in rows)
                 runs = [r for r in rows if r["Name"].startswith("k_msm_runs_affine")]
                 if runs and tot:
-                    k["runs_time_share"] = round(float(runs[0]["TotalDurationNs"]) / tot, 4)
-                    k["runs_avg_ms"] = round(float(runs[0]["AverageNs"]) / 1e6, 4)
-                    k["runs_source"] = "profiles/%s_raw/kt_msm_2p21_kernel_stats.csv (share of the summed kernel time of a step)" % tag
+                    k["runs"][str(units_n)] = {"time_share": round(float(runs[0]["TotalDurationNs"]) / tot, 4), "avg_ms": round(float(runs[0]["AverageNs"]) / 1e6, 4),
+                                               "source": "profiles/%s_raw/kt_msm_%s_kernel_stats.csv (k_msm_runs_affine over the summed kernel time of a step)" % (tag, units_tag)}
         for name in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                      "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
                      "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
