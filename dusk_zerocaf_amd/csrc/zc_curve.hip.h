@@ -419,14 +419,88 @@ ZC_DI fe fp_pow_var(const fe& a, const fe& e)
     }
     return acc;
 }
-// legendre_symbol (field.rs:703-706): Choice(0) iff a^((p-1)/2) == -1 (so 0 maps to 1)
-ZC_DI bool fp_legendre(const fe& a)
+// legendre_symbol (field.rs:703-706): Choice(0) iff a^((p-1)/2) == -1 (so 0 maps to 1).
+// The reference's way, an exponentiation: a^q = a w^2 with w = a^((q-1)/2), p - 1 = 4 q, then (a^q)^2.
+ZC_DI bool fp_legendre_pow(const fe& a)
 {
     const fe w = fp_pow_p58(a);      // a^((q-1)/2)
     const fe t = fp_mul(fp_mul(a, w), w);                         // a^q
     fe one = fe_zero();
     one.v[0] = 1;
     return !fe_eq_canon(fp_canon(fp_sqr(t)), fe_n_minus_canon<FP>(one));
+}
+// The same bit as the JACOBI symbol (a / p) on the division-step machinery of the inversion above -- no field
+// multiplication at all.  Positive division steps (f, g >= 0 throughout, so the symbol's sign rules stay the textbook
+// ones):  g odd and eta < 0: swap f, g (sign flips when both are 3 mod 4);  g odd: g += f;  then g /= 2 (sign flips when
+// f is 3 or 5 mod 8), eta -= 1.  30 steps on the low words, one 2x2 matrix applied to the full-width (f, g) -- only f
+// and g: the symbol needs no Bezout coefficients, so a round is half an inversion round.  The walk ends when f = 1:
+// (g / 1) = 1 and the collected sign is the symbol.  Unlike the signed steps of the inversion this variant has no proven
+// step bound (random 252-bit inputs: 23-28 rounds, 831 steps at most in 3 x 10^4 trials), so the loop runs until every lane
+// of the wave is done, at most `max_rounds` rounds, and a lane that is not falls back to the exponentiation (tests force
+// that path with a small bound).  a = 0 (gcd p, f never 1) is answered up front.
+#if defined(__HIP_DEVICE_COMPILE__)
+ZC_DI bool wave_all(bool x) { return __all(x) != 0; }
+ZC_DI bool wave_any(bool x) { return __any(x) != 0; }
+#else
+ZC_DI bool wave_all(bool x) { return x; }
+ZC_DI bool wave_any(bool x) { return x; }
+#endif
+ZC_DI int32_t sgcd_posdivsteps30(int32_t eta, u32 f, u32 g, sgcd_mat& t, u32& jac)
+{
+    u32 u = 1, v = 0, q = 0, r = 1;
+#pragma unroll 6
+    for (int i = 0; i < 30; i++) {
+        const u32 godd = 0u - (g & 1u);
+        const u32 swap = godd & (u32)(eta >> 31);                // g odd and eta < 0
+        jac ^= swap & ((f & g) >> 1);                            // both 3 mod 4 (bit 0 of jac is the sign)
+        u32 x = (f ^ g) & swap;
+        f ^= x; g ^= x;
+        x = (u ^ q) & swap;
+        u ^= x; q ^= x;
+        x = (v ^ r) & swap;
+        v ^= x; r ^= x;
+        eta = (int32_t)(((u32)eta ^ swap) - swap);               // negated on a swap
+        g += f & godd;
+        q += u & godd;
+        r += v & godd;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+        eta -= 1;
+        jac ^= (f >> 1) ^ (f >> 2);                              // (2 / f) = -1 for f = 3, 5 mod 8
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return eta;
+}
+constexpr int JACOBI_MAX_ROUNDS = 40;
+// a: R-class Montgomery value.  true unless (a / p) = -1.
+ZC_DI bool fp_legendre(const fe& a, int max_rounds = JACOBI_MAX_ROUNDS)
+{
+    const fe c = fp_canon(a);
+    int32_t f[9], g[9];
+    sgcd_pack30(g, c);
+#pragma unroll
+    for (int i = 0; i < 9; i++) f[i] = sgcd_mod<FP>::limb(i);
+    bool done = fe_is_zero_canon(c), res = true;
+    int32_t eta = -1;
+    u32 jac = 0;
+#pragma unroll 1
+    for (int round = 0; round < max_rounds; round++) {
+        if (wave_all(done)) break;
+        sgcd_mat t;
+        eta = sgcd_posdivsteps30(eta, (u32)f[0] | ((u32)f[1] << 30), (u32)g[0] | ((u32)g[1] << 30), t, jac);
+        sgcd_update_fg(f, g, t);
+        const int32_t rest = f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7] | f[8];
+        if (!done && f[0] == 1 && rest == 0) {                   // later rounds of the wave's other lanes walk on from here: keep the answer
+            done = true;
+            res = (jac & 1u) == 0;
+        }
+    }
+    if (wave_any(!done)) {
+        const bool slow = fp_legendre_pow(a);
+        if (!done) res = slow;
+    }
+    return res;
 }
 
 // ---------------------------------------------------------------- points

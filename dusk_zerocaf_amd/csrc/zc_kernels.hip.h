@@ -269,11 +269,11 @@ ZC_KERNEL void k_fe_pow(const u64* a, const u64* e, u64* out, size_t n)         
     load5(l, e + 5 * i);
     fe_store_canon<FP>(out + 5 * i, fp_pow_var(fe_load_mont<FP>(a + 5 * i), fe_from_limbs52(l)));
 }
-ZC_KERNEL void k_fe_legendre(const u64* a, uint8_t* out, size_t n)
+ZC_KERNEL void k_fe_legendre(const u64* a, uint8_t* out, size_t n, int max_rounds)     // field.rs:703-706, as a Jacobi symbol
 {
     const size_t i = gid();
     if (i >= n) return;
-    out[i] = fp_legendre(fe_load_mont<FP>(a + 5 * i)) ? 1 : 0;
+    out[i] = fp_legendre(fe_load_mont<FP>(a + 5 * i), max_rounds) ? 1 : 0;
 }
 ZC_KERNEL void k_fe_is_positive(const u64* a, uint8_t* out, size_t n)              // field.rs:552-557 (limb-lexicographic)
 {

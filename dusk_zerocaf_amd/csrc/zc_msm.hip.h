@@ -48,7 +48,14 @@ namespace zc {
 // buckets, long ones spend fewer doublings' worth of work on the (first mod 2^(c-1)) * acc products.
 // Measured (2^16 / 2^18 / 2^20 / 2^21 / 2^24 pairs, ms): 8: 1.10 / 1.50 / 2.81 / 4.53 / 24.75,
 // 16: 1.17 / 1.55 / 2.77 / 4.42 / 24.40, 32: 1.30 / 1.68 / 2.93 / 4.56 / 24.05.
-inline int msm_segment_buckets(size_t nbuckets) { return nbuckets <= ((size_t)1 << 18) ? 8 : nbuckets >= ((size_t)1 << 21) ? 32 : 16; }
+inline int msm_segment_buckets(size_t nbuckets)
+{
+    if (const char* e = getenv("ZC_MSM_SEG")) {                // tuning: 2, 4, 8, ... (a power of two)
+        const int f = atoi(e);
+        if (f >= 2 && f <= 256 && (f & (f - 1)) == 0) return f;
+    }
+    return nbuckets <= ((size_t)1 << 18) ? 8 : nbuckets >= ((size_t)1 << 21) ? 32 : 16;
+}
 constexpr int MSM_SCALAR_BITS = 261;   // 260-bit limb patterns + the carry of the signed recoding
 constexpr int MSM_MIN_C = 5, MSM_MAX_C = 22;
 

@@ -1015,7 +1015,20 @@ static int fe_flag_op(zc_ctx* ctx, void (*k)(const u64*, uint8_t*, size_t), cons
         hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt);
     });
 }
-int zc_fe_legendre_symbol(zc_ctx* c, const uint64_t* a, uint8_t* o, size_t n) { return fe_flag_op(c, zc::k_fe_legendre, a, o, n); }
+// ZC_JACOBI_ROUNDS=r (tests): rounds of 30 positive division steps before a lane falls back to the exponentiation
+int zc_fe_legendre_symbol(zc_ctx* ctx, const uint64_t* a, uint8_t* out, size_t n)
+{
+    REQUIRE(a); REQUIRE(out);
+    int rounds = zc::JACOBI_MAX_ROUNDS;
+    if (const char* e = getenv("ZC_JACOBI_ROUNDS")) {
+        const int f = atoi(e);
+        if (f >= 0 && f <= 200) rounds = f;
+    }
+    Arg args[2] = {in_arg(a, 40), out_arg(out, 1)};
+    return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        hipLaunchKernelGGL(zc::k_fe_legendre, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt, rounds);
+    });
+}
 int zc_fe_is_positive(zc_ctx* c, const uint64_t* a, uint8_t* o, size_t n) { return fe_flag_op(c, zc::k_fe_is_positive, a, o, n); }
 int zc_fe_mod_sqrt(zc_ctx* ctx, const uint64_t* a, int sign, uint64_t* out, uint8_t* ok, size_t n)
 {

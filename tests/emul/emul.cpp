@@ -83,6 +83,16 @@ void emul_fe_invert(const u64* a, u64* out, uint8_t* ok, size_t n)
         fe_store_canon<FP>(out + 5 * i, fp_invert(x));
     }
 }
+// legendre_symbol as the Jacobi symbol on positive division steps (max_rounds rounds, then the exponentiation),
+// and the exponentiation alone; `rounds_out` (may be null): not available on the host build, kept 0
+void emul_fe_legendre(const u64* a, uint8_t* jac, uint8_t* pw, size_t n, int max_rounds)
+{
+    for (size_t i = 0; i < n; i++) {
+        const fe x = fe_load_mont<FP>(a + 5 * i);
+        jac[i] = fp_legendre(x, max_rounds) ? 1 : 0;
+        pw[i] = fp_legendre_pow(x) ? 1 : 0;
+    }
+}
 void emul_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* sq, size_t n)
 {
     for (size_t i = 0; i < n; i++) {

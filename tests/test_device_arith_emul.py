@@ -91,6 +91,19 @@ def test_emul_invert_sqrt_ratio(emul, oracle):
     assert np.array_equal(sq, wsq) and np.array_equal(out[:120], want)
 
 
+def test_emul_legendre_is_the_jacobi_symbol(emul, oracle):
+    """legendre_symbol (field.rs:703-706) on the division-step machinery: the Jacobi-symbol walk, the exponentiation it
+    replaces and the oracle agree; with a round bound too small to finish, the fallback answers."""
+    vals = V.rand_fe(400, V.SEED + 40) + [(x * x) % pm.P for x in V.rand_fe(100, V.SEED + 41)] + [2 ** k for k in range(0, 252, 7)]
+    a = V.limbs_array(vals)
+    want = oracle.fe_legendre_symbol(a)
+    assert 0 < int(want.sum()) < len(a)                               # both answers occur
+    for rounds in (40, 26, 3, 0):                                      # 26: some lanes unfinished; 3, 0: all fall back
+        jac, pw = np.empty(len(a), dtype=np.uint8), np.empty(len(a), dtype=np.uint8)
+        emul.emul_fe_legendre(p(a), p(jac), p(pw), C.c_size_t(len(a)), rounds)
+        assert np.array_equal(jac, want) and np.array_equal(pw, want), rounds
+
+
 def test_emul_point_ops(emul, oracle):
     n = 48
     P = V.base_multiples(oracle, n, V.SEED + 6)

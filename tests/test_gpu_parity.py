@@ -303,7 +303,7 @@ def test_sqrt_ratio_bulk(eng, oracle):
     assert eq(sq, wsq) and eq(out, want) and 0 < sq.sum() < n
 
 
-def test_field_f8_rows(eng, oracle, kats):
+def test_field_f8_rows(eng, oracle, kats, monkeypatch):
     """F7/F8/F9 leftovers: Div, Half, Pow, legendre_symbol, ModSqrt (both signs), is_positive --
     reference KATs (division, a_pow_b, legendre_symbol, mod_sqrt_tonelli_shanks) and bulk parity."""
     f = lambda n: np.array([kats["field"][n]["limbs"]], dtype=np.uint64)
@@ -328,6 +328,18 @@ def test_field_f8_rows(eng, oracle, kats):
     assert eq(ok, wok) and eq(got, want)
     assert eq(eng.fe_half(x), oracle.fe_half(x))
     assert eq(eng.fe_legendre_symbol(x), oracle.fe_legendre_symbol(x))
+    # legendre_symbol runs as a Jacobi symbol on positive division steps; a lane the round bound leaves unfinished falls
+    # back to the exponentiation: bounds that finish every / some / no lane give the same answers
+    big = V.rand_fe_np(1 << 16, V.SEED + 323)
+    big[::97] = 0
+    wl = oracle.mt(oracle.fe_legendre_symbol, big)
+    for rounds in (None, 26, 2):
+        if rounds is None:
+            monkeypatch.delenv("ZC_JACOBI_ROUNDS", raising=False)
+        else:
+            monkeypatch.setenv("ZC_JACOBI_ROUNDS", str(rounds))
+        assert eq(eng.fe_legendre_symbol(big), wl), rounds
+    monkeypatch.delenv("ZC_JACOBI_ROUNDS", raising=False)
     assert eq(eng.fe_is_positive(x), oracle.fe_is_positive(x))
     raw = np.random.default_rng(V.SEED + 142).integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)       # non-canonical limbs too
     assert eq(eng.fe_is_positive(raw), oracle.fe_is_positive(raw))
