@@ -744,8 +744,14 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 //   * tickets and flags of one XCD live in cache lines no other XCD touches, holder and successor of a
 //     slot run on the same XCD by construction, flags are stored and polled with agent-scope accesses
 //     (`sc1`: past the L1 of the CU) -- the per-XCD L2 they meet in is coherent for its own CUs;
-//   * a holder never waits for a later ticket, so the waits cannot cycle; the spin is bounded anyway
-//     (trap after ~4 s, which surfaces as a HIP error at the next synchronisation).
+//   * a holder never waits for a later ticket, so the waits cannot cycle; the spin is bounded anyway: a wave that
+//     has polled for ~4 s sets the launch's error word (RING_ERR_WORD) and goes on without the slot -- its
+//     outputs are garbage, the context stays usable, and the host reports ZC_ERR_HIP at the next
+//     synchronisation of that device (zerocaf_hip.hip: ring_check; no trap, so no sticky HIP error).
+// Invariants the host side keeps (fast_ring): ONE stream per device state orders every user of the ring;
+// tickets and flags are zeroed on that stream before every launch (the generation field of the parked word
+// has 19 bits: a launch hands out fewer than 2^19 * slots tickets per XCD, i.e. at most slots * 2^25 lanes --
+// fast_ring cuts longer batches into several launches); the error word is cleared only when it is read.
 // (A persistent grid -- 768 resident workgroups walking the tiles, 192 MB of tables -- was measured
 // 14 % SLOWER: co-resident waves then start together, stay in lock step and stall on their table
 // loads together; short-lived workgroups drift apart and cover each other.  The ring keeps the
@@ -753,7 +759,9 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 constexpr u32 RING_XCDS = 8;                      // HW_REG_XCC_ID is masked to this range
 constexpr u32 RING_SLOTS = 512;                   // wave slots per XCD
 constexpr u32 RING_TICKET_STRIDE = 32;            // one 128-byte line per XCD's ticket counter
-constexpr u32 RING_STATE_WORDS = RING_XCDS * RING_TICKET_STRIDE + RING_XCDS * RING_SLOTS;
+constexpr u32 RING_STATE_WORDS = RING_XCDS * RING_TICKET_STRIDE + RING_XCDS * RING_SLOTS;   // zeroed per launch
+constexpr u32 RING_ERR_WORD = RING_STATE_WORDS;    // behind them: set by a wave that gave up waiting (sticky until read)
+constexpr u32 RING_ALLOC_WORDS = RING_STATE_WORDS + 32;
 constexpr size_t RING_TABLE_BYTES = (size_t)RING_XCDS * RING_SLOTS * 64 * 1024;
 
 // The lane's number, computed afresh wherever it is asked for: `volatile` keeps the compiler from sharing
@@ -794,7 +802,10 @@ ZC_DI ring_table ring_acquire(u32* __restrict__ table, u32* __restrict__ state, 
             const u32 f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(state + flag_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (f >= gen) break;
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 22)) __builtin_trap();
+            if (++spins > (1u << 22)) {                   // give up: flag the launch, go on without the slot
+                if (lane == 0) __hip_atomic_store(state + RING_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
     }
     return ring_table{table + (size_t)(xcc * RING_SLOTS + slot) * (64 * 256)};

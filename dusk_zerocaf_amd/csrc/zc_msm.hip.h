@@ -339,6 +339,24 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     fetch(vcur);
     uint2 nxt = (lo + 1 < hi) ? pairs[lo + 1] : make_uint2(none, 0);
     bool first = true;
+#ifdef ZC_MSM_PROBE_PURE        // timing probe only (wrong sums): the additions alone -- one record, no loads, waits or LDS inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    niels q0;
+    q0.ymx = unpack256(base[0 * 64 + lane], base[1 * 64 + lane]);
+    q0.ypx = unpack256(base[2 * 64 + lane], base[3 * 64 + lane]);
+    q0.z = fe_zero();
+    q0.t2d = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
+    for (u32 e = lo; e < hi; e++) {
+        acc = pt_add_cached<ZC_MSM_ACC_ILP, AFFINE>(acc, niels_cond_neg((e & 1) != 0, q0));
+        const bool last = e + 1 == hi;
+        if (last || (e & 31) == 31) {
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
+            acc = pt_identity();
+            first = false;
+        }
+    }
+    return;
+#endif
     for (u32 e = lo; e < hi; e++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         niels q;

@@ -63,8 +63,9 @@ struct DevState {
     size_t msm_bytes = 0;
     void* fast = nullptr;               // windowed-core tables: ring of wave slots, 256 MB (zc_kernels.hip.h)
     size_t fast_bytes = 0;
-    void* ring = nullptr;               // tickets and slot flags of the table ring
+    void* ring = nullptr;               // tickets and slot flags of the table ring (+ its error word)
     size_t ring_bytes = 0;
+    bool ring_used = false;             // a windowed-core launch since the error word was last read
     void* base_table = nullptr;         // comb table of the basepoint: 33 x 128 cached affine points
     size_t base_bytes = 0;
     void* part = nullptr;               // MSM exchange: gathered per-rank / per-device partials + the folded result
@@ -97,6 +98,8 @@ struct zc_ctx {
 };
 
 namespace {
+
+int ring_check(struct DevState& D);     // windowed-core table ring: error word of the last launches (defined with fast_ring)
 
 // One buffer argument of a batched call.
 struct Arg {
@@ -273,6 +276,7 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bo
             HIP_TRY(hipStreamSynchronize(ds.copy_in));
             HIP_TRY(hipStreamSynchronize(ds.s()));
             HIP_TRY(hipStreamSynchronize(ds.copy_out));
+            if (!rc) rc = ring_check(ds);
             return rc;
         };
         const int rc = body();
@@ -399,13 +403,36 @@ int fast_ring(DevState& D, size_t cnt, L&& launch)
 {
     int rc = ensure(&D.fast, &D.fast_bytes, zc::RING_TABLE_BYTES);
     if (rc) return rc;
-    rc = ensure(&D.ring, &D.ring_bytes, zc::RING_STATE_WORDS * sizeof(zc::u32));
-    if (rc) return rc;
-    for (size_t off = 0; off < cnt; off += FAST_MAX_LAUNCH) {
-        HIP_TRY(hipMemsetAsync(D.ring, 0, zc::RING_STATE_WORDS * sizeof(zc::u32), D.s()));
-        launch((zc::u32*)D.fast, (zc::u32*)D.ring, ring_slots(), off, std::min(FAST_MAX_LAUNCH, cnt - off));
+    if (!D.ring) {
+        rc = ensure(&D.ring, &D.ring_bytes, zc::RING_ALLOC_WORDS * sizeof(zc::u32));
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(D.ring, 0, zc::RING_ALLOC_WORDS * sizeof(zc::u32), D.s()));     // the error word starts clear
     }
+    // a launch hands out fewer than 2^19 generations of its slots (the 19-bit field of the word ring_acquire parks)
+    const zc::u32 slots = ring_slots();
+    const size_t max_launch = std::min(FAST_MAX_LAUNCH, (size_t)slots << 24);
+    for (size_t off = 0; off < cnt; off += max_launch) {
+        HIP_TRY(hipMemsetAsync(D.ring, 0, zc::RING_STATE_WORDS * sizeof(zc::u32), D.s()));
+        launch((zc::u32*)D.fast, (zc::u32*)D.ring, slots, off, std::min(max_launch, cnt - off));
+    }
+    D.ring_used = true;
+    if (getenv("ZC_TEST_RING_POISON"))                         // tests: pretend a wave gave up (exercises ring_check's report-and-recover path)
+        HIP_TRY(hipMemsetAsync((zc::u32*)D.ring + zc::RING_ERR_WORD, 1, 1, D.s()));
     return ZC_OK;
+}
+// After a synchronisation of D's stream: did a wave of a windowed-core launch give up waiting for its table slot
+// (zc_kernels.hip.h: ring_acquire)?  Reads and clears the error word; the context stays usable.
+int ring_check(DevState& D)
+{
+    if (!D.ring_used || !D.ring) return ZC_OK;
+    D.ring_used = false;
+    zc::u32 err = 0;
+    zc::u32* word = (zc::u32*)D.ring + zc::RING_ERR_WORD;
+    HIP_TRY(hipMemcpyAsync(&err, word, sizeof(err), hipMemcpyDeviceToHost, D.s()));
+    HIP_TRY(hipStreamSynchronize(D.s()));
+    if (!err) return ZC_OK;
+    HIP_TRY(hipMemsetAsync(word, 0, sizeof(err), D.s()));
+    return fail(ZC_ERR_HIP, "windowed core: a wave timed out waiting for its table slot; the outputs of the last windowed-core calls on this device are not valid");
 }
 int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
 {
@@ -952,6 +979,8 @@ int zc_ctx_synchronize(zc_ctx* ctx)
     for (auto& ds : ctx->devs) {
         HIP_TRY(hipSetDevice(ds.device));
         HIP_TRY(hipStreamSynchronize(ds.s()));
+        const int rc = ring_check(ds);
+        if (rc) return rc;
     }
     return ZC_OK;
 }

@@ -747,6 +747,32 @@ def test_windowed_core_table_ring_under_contention(eng, oracle, monkeypatch):
     assert eq(out, ref_out) and eq(ok, ref_ok)
 
 
+def test_windowed_core_ring_timeout_is_reported_and_the_context_survives(eng, monkeypatch):
+    """A wave that gives up waiting for its table slot sets the ring's error word instead of trapping (a trap is a
+    sticky HIP error that kills every later call of the process).  The host reads the word at the next
+    synchronisation of the device, reports ZC_ERR_HIP once, clears it, and the context keeps working.  The hook
+    ZC_TEST_RING_POISON sets the word the way a timed-out wave would."""
+    import dusk_zerocaf_amd as z
+    n = 4096
+    K = V.rand_scalars_np(n, V.SEED + 143, bits=252)
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 144, bits=249))
+    good = eng.ed_scalar_mul(P, K, flags=z.FAST)
+    monkeypatch.setenv("ZC_TEST_RING_POISON", "1")
+    with pytest.raises(Exception, match="table slot"):
+        eng.ed_scalar_mul(P, K, flags=z.FAST)                      # host batch: synchronises, sees the word
+    monkeypatch.delenv("ZC_TEST_RING_POISON")
+    assert eq(eng.ed_scalar_mul(P, K, flags=z.FAST), good)         # reported once, cleared, context intact
+    import torch
+    dP, dK = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, K))
+    monkeypatch.setenv("ZC_TEST_RING_POISON", "1")
+    eng.ed_scalar_mul(dP, dK, flags=z.FAST)                        # device batch: asynchronous, no report yet
+    monkeypatch.delenv("ZC_TEST_RING_POISON")
+    with pytest.raises(Exception, match="table slot"):
+        eng.synchronize()
+    eng.synchronize()
+    assert eq(eng.ed_scalar_mul(dP, dK, flags=z.FAST).cpu().numpy().view(np.uint64), good)
+
+
 def test_next_rows_elligator_validity_projective(eng, oracle, kats):
     """Elligator + from_uniform_bytes, is_valid (Edwards and Ristretto),
     ProjectivePoint add/double -- limb-exact vs the oracle, reference KATs included."""
