@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: batched variable-base Edwards scalar multiplication
 (BASELINE.json configs[2]: 2^20 points x random 252-bit scalars per GPU) on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W          (defaults: K = 20, W = 5 -- the driver's own invocation; 0.5 s)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of zc_ed_scalar_mul (strict mode: the reference's formula sequence,
@@ -184,8 +184,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)          # the defaults are the driver's own invocation (--steps 20 --warmup 5):
+    ap.add_argument("--warmup", type=int, default=5)         # five launches take a cold board past its clock / power transient
     ap.add_argument("--units", "--n", dest="n", type=int, default=1 << 20, help="units per GPU per step")
     ap.add_argument("--workload", default="scalar_mul", choices=list(WORKLOADS))
     ap.add_argument("--scalar-bits", type=int, default=252, choices=[249, 252],

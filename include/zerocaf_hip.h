@@ -82,6 +82,10 @@ int zc_ctx_set_stream(zc_ctx *ctx, void *hip_stream, int external);
 /* the same for device slot `slot` (index into the `devices` array of zc_ctx_create).  A switch
  * orders everything already enqueued on the old stream before later work on the new one.       */
 int zc_ctx_set_stream_dev(zc_ctx *ctx, int slot, void *hip_stream, int external);
+/* Waits for the streams of every device slot.  Also the place where the one asynchronous error of the
+ * library surfaces for callers that only pass device pointers: a wave of the windowed core (ZC_SCALAR_MUL_FAST,
+ * zc_ris_roundtrip_mul) that timed out on its table slot -- a wedged device -- is reported here (and by every
+ * host-pointer call, which synchronises anyway) as ZC_ERR_HIP, once; the context stays usable.               */
 int zc_ctx_synchronize(zc_ctx *ctx);
 int zc_device_count(void);
 /* Pin / unpin a caller-owned host buffer (hipHostRegister): host batches from pinned memory copy
