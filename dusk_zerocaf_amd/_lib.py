@@ -77,8 +77,10 @@ SIGNATURES = {
     "zc_ed_coset4": [_u64p, _u64p, _n],
     "zc_ed_mul_base": [_u64p, _u64p, _n],
     "zc_ris_mul_base_compress": [_u64p, _u8p, _n],
+    "zc_ed_mul_base_wnaf": [_u64p, C.c_uint, _u64p, _n],
     "zc_msm": [_u64p, _u64p, _n, _u64p],
     "zc_msm_partial": [_u64p, _u64p, _n, _u64p],
+    "zc_msm_plan": [_n, C.c_int, C.POINTER(C.c_int32)],
     "zc_ed_fold_ordered": [_u64p, _n, _u64p],
     "zc_msm_sharded": [_u64p, _u64p, _n, _u64p],
     "zc_comm_init": [_u8p, C.c_int, C.c_int],
@@ -120,17 +122,8 @@ def _share_hip_runtime_with_torch() -> None:
                 pass
 
 
-def load() -> C.CDLL:
-    """Load the HIP library.  Fails loudly when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ZerocafHipError(
-            "libzerocaf_hip.so is missing (%s): build it with `python -m dusk_zerocaf_amd.build`; "
-            "there is no CPU fallback" % LIB_PATH)
-    _share_hip_runtime_with_torch()
-    lib = C.CDLL(LIB_PATH)
+def _bind(path: str) -> C.CDLL:
+    lib = C.CDLL(path)
     lib.zc_ctx_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_ctx)]
     lib.zc_ctx_create.restype = C.c_int
     lib.zc_ctx_destroy.argtypes = [_ctx]
@@ -146,10 +139,43 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = [_ctx] + sig
         fn.restype = C.c_int
-    _lib = lib
     return lib
 
 
-def check(rc: int, what: str) -> None:
+def load() -> C.CDLL:
+    """Load the HIP library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZerocafHipError(
+            "libzerocaf_hip.so is missing (%s): build it with `python -m dusk_zerocaf_amd.build`; "
+            "there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
+    _lib = _bind(LIB_PATH)
+    return _lib
+
+
+TEST_LIB_PATH = os.path.join(HERE, "libzerocaf_hip_test.so")
+_test_lib = None
+
+
+def load_test_hooks() -> C.CDLL:
+    """libzerocaf_hip_test.so: the same sources built with -DZC_TEST_HOOKS (fault injection for the table ring,
+    the MSM's sort stage on its own).  For tests/ only -- nothing in the product path loads it."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise ZerocafHipError("libzerocaf_hip_test.so is missing: build it with `python -m dusk_zerocaf_amd.build`")
+        _share_hip_runtime_with_torch()
+        _test_lib = _bind(TEST_LIB_PATH)
+        _test_lib.zc_test_msm_sort.argtypes = [_ctx, _u64p, _n, C.c_int, C.c_void_p]
+        _test_lib.zc_test_msm_sort.restype = C.c_int
+        _test_lib.zc_test_odd_table.argtypes = [_ctx, C.c_void_p]
+        _test_lib.zc_test_odd_table.restype = C.c_int
+    return _test_lib
+
+
+def check(rc: int, what: str, lib=None) -> None:
     if rc != 0:
-        raise ZerocafHipError("%s failed: status %d (%s)" % (what, rc, load().zc_last_error().decode()))
+        raise ZerocafHipError("%s failed: status %d (%s)" % (what, rc, (lib or load()).zc_last_error().decode()))

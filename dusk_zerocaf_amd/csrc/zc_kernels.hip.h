@@ -431,6 +431,30 @@ ZC_KERNEL void k_sc_into_bits(const u64* a, uint8_t* out, size_t n)             
 // k = k - Scalar::from(k_i) } ; k = half_without_mod(k) }, where Scalar::from of a negative digit is L - |k_i|
 // (scalar.rs:68-84) and Sub adds L back only after a borrow (:210-237) -- so a scalar above L - |k_i| takes the
 // reference's wrap-around, not the integer NAF.  256 digits per scalar, zeros behind the last one.
+// one iteration of that loop: the digit, k updated in place (m = the limbs of L)
+ZC_DI int naf_step(u64 (&k)[5], const u64 (&m)[5], u32 width)
+{
+    int ki = 0;
+    if (((k[0] | k[1] | k[2] | k[3] | k[4]) != 0) && (k[0] & 1)) {
+        if (width == 0) ki = 2 - (int)(k[0] & 3);
+        else {
+            const int modulus = (int)(k[0] & ((1u << width) - 1u));                      // mods_2_pow_k, scalar.rs:433-442
+            ki = modulus >= (1 << (width - 1)) ? modulus - (1 << width) : modulus;
+        }
+        u64 t[5] = {(u64)(ki < 0 ? -ki : ki), 0, 0, 0, 0}, r[5];
+        if (ki < 0) {
+            const u64 z[5] = {0, 0, 0, 0, 0};
+            sub52(r, z, t, m);                                                           // Neg: 0 - |k_i| mod L
+#pragma unroll
+            for (int j = 0; j < 5; j++) t[j] = r[j];
+        }
+        sub52(r, k, t, m);
+#pragma unroll
+        for (int j = 0; j < 5; j++) k[j] = r[j];
+    }
+    half_without_mod52(k);
+    return ki;
+}
 ZC_KERNEL void k_sc_compute_naf(const u64* a, u32 width, int8_t* out, size_t n)
 {
     const size_t i = gid();
@@ -441,25 +465,7 @@ ZC_KERNEL void k_sc_compute_naf(const u64* a, u32 width, int8_t* out, size_t n)
     u32* o = reinterpret_cast<u32*>(out + 256 * i);
     u32 packed = 0;
     for (int d = 0; d < 256; d++) {
-        int ki = 0;
-        if (((k[0] | k[1] | k[2] | k[3] | k[4]) != 0) && (k[0] & 1)) {
-            if (width == 0) ki = 2 - (int)(k[0] & 3);
-            else {
-                const int modulus = (int)(k[0] & ((1u << width) - 1u));                  // mods_2_pow_k, scalar.rs:433-442
-                ki = modulus >= (1 << (width - 1)) ? modulus - (1 << width) : modulus;
-            }
-            u64 t[5] = {(u64)(ki < 0 ? -ki : ki), 0, 0, 0, 0}, r[5];
-            if (ki < 0) {
-                const u64 z[5] = {0, 0, 0, 0, 0};
-                sub52(r, z, t, m);                                                       // Neg: 0 - |k_i| mod L
-#pragma unroll
-                for (int j = 0; j < 5; j++) t[j] = r[j];
-            }
-            sub52(r, k, t, m);
-#pragma unroll
-            for (int j = 0; j < 5; j++) k[j] = r[j];
-        }
-        half_without_mod52(k);
+        const int ki = naf_step(k, m, width);
         packed |= ((u32)ki & 0xFFu) << (8 * (d & 3));
         if ((d & 3) == 3) {
             o[d >> 2] = packed;
@@ -745,9 +751,11 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 //     slot run on the same XCD by construction, flags are stored and polled with agent-scope accesses
 //     (`sc1`: past the L1 of the CU) -- the per-XCD L2 they meet in is coherent for its own CUs;
 //   * a holder never waits for a later ticket, so the waits cannot cycle; the spin is bounded anyway: a wave that
-//     has polled for ~4 s sets the launch's error word (RING_ERR_WORD) and goes on without the slot -- its
-//     outputs are garbage, the context stays usable, and the host reports ZC_ERR_HIP at the next
-//     synchronisation of that device (zerocaf_hip.hip: ring_check; no trap, so no sticky HIP error).
+//     has polled for ~4 s GIVES UP: it sets the device's error word (pinned host memory; its device address is
+//     parked behind the ring state at RING_ERR_WORD), touches no table slot, never publishes its generation (its
+//     successors on that slot give up in turn: fail closed), writes POISON into the rows it owns (limbs / bytes of
+//     all ones, ok = 0) and ends.  The context stays usable: the host reports ZC_ERR_HIP at the next entry point
+//     or synchronisation that touches the device (zerocaf_hip.hip: ring_check; no trap, so no sticky HIP error).
 // Invariants the host side keeps (fast_ring): ONE stream per device state orders every user of the ring;
 // tickets and flags are zeroed on that stream before every launch (the generation field of the parked word
 // has 19 bits: a launch hands out fewer than 2^19 * slots tickets per XCD, i.e. at most slots * 2^25 lanes --
@@ -760,7 +768,7 @@ constexpr u32 RING_XCDS = 8;                      // HW_REG_XCC_ID is masked to 
 constexpr u32 RING_SLOTS = 512;                   // wave slots per XCD
 constexpr u32 RING_TICKET_STRIDE = 32;            // one 128-byte line per XCD's ticket counter
 constexpr u32 RING_STATE_WORDS = RING_XCDS * RING_TICKET_STRIDE + RING_XCDS * RING_SLOTS;   // zeroed per launch
-constexpr u32 RING_ERR_WORD = RING_STATE_WORDS;    // behind them: set by a wave that gave up waiting (sticky until read)
+constexpr u32 RING_ERR_WORD = RING_STATE_WORDS;    // behind them (two words, written once by the host): device address of the error word
 constexpr u32 RING_ALLOC_WORDS = RING_STATE_WORDS + 32;
 constexpr size_t RING_TABLE_BYTES = (size_t)RING_XCDS * RING_SLOTS * 64 * 1024;
 
@@ -775,7 +783,7 @@ ZC_DI u32 lane_id_fresh()
 }
 // A wave's slot: 64 KB starting at `base` (wave-uniform: scalar registers), lane l owns [l KB, (l + 1) KB).
 struct ring_table {
-    u32* base;
+    u32* base;                                    // nullptr: the wave gave up waiting (wave-uniform)
     ZC_DI u32* entry(int j) const
     {
         return base + (lane_id_fresh() * 256u + 32u * (u32)j);
@@ -793,6 +801,12 @@ ZC_DI ring_table ring_acquire(u32* __restrict__ table, u32* __restrict__ state, 
     u32 t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(state + RING_TICKET_STRIDE * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
+#ifdef ZC_TEST_HOOKS                              // test build: the upper half of the argument shortens the spin (waves really give up)
+    const u32 spin_limit = 1u << ((slots >> 16) ? (slots >> 16) : 22u);
+    slots &= 0xFFFFu;
+#else
+    const u32 spin_limit = 1u << 22;
+#endif
     const u32 slot = t % slots, gen = t / slots;          // slots <= RING_SLOTS (fewer only to exercise the waits in tests)
     const u32 flag_word = RING_XCDS * RING_TICKET_STRIDE + xcc * RING_SLOTS + slot;
     if (lane == 0) *hold = flag_word | ((gen + 1) << 13);
@@ -802,9 +816,12 @@ ZC_DI ring_table ring_acquire(u32* __restrict__ table, u32* __restrict__ state, 
             const u32 f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(state + flag_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (f >= gen) break;
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 22)) {                   // give up: flag the launch, go on without the slot
-                if (lane == 0) __hip_atomic_store(state + RING_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+            if (++spins > spin_limit) {                   // give up: flag the device, take no slot (the caller writes poison and ends)
+                if (lane == 0) {
+                    u32* err = *reinterpret_cast<u32* const*>(state + RING_ERR_WORD);
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return ring_table{nullptr};
             }
         }
     }
@@ -832,6 +849,11 @@ ZC_KERNEL_3W void k_ed_scalar_mul_fast(const u64* p, const u64* k, u32 k_stride,
     top = wave_max_small(top);
     __shared__ u32 hold[ZC_BLOCK / 64];
     const ring_table mine = ring_acquire(table, ring, hold + (tid >> 6), ring_slots);
+    if (!mine.base) {                                      // the wave gave up waiting for its table slot (wave-uniform): poison, no barrier follows
+        if (valid)
+            for (int j = 0; j < 20; j++) out[20 * (size_t)i + j] = ~(u64)0;
+        return;
+    }
     const pt Q = scalar_mul_fast(pt_load(p + 20 * (size_t)ii), mine, sdig + tid, ZC_BLOCK, top);
     ring_release(ring, hold + (threadIdx.x >> 6));
     if (valid) pt_store(out + 20 * (size_t)i, Q);
@@ -856,6 +878,14 @@ ZC_KERNEL_3W void k_ris_roundtrip_mul_fast(const uint8_t* in, const u64* k, uint
     top = wave_max_small(top);
     __shared__ u32 hold[ZC_BLOCK / 64];                    // the table slot is held for the multiplication only
     const ring_table mine = ring_acquire(table, ring, hold + wave_in_block, ring_slots);
+    if (!mine.base) {                                      // the wave gave up waiting for its table slot (wave-uniform): poison, no barrier follows
+        if (valid) {
+            w[0] = w[1] = w[2] = w[3] = ~(u64)0;
+            store_words256(out + 32 * (size_t)i, w);
+            if (ok) ok[i] = 0;
+        }
+        return;
+    }
     pt Q = scalar_mul_fast(P, mine, sdig + tid, ZC_BLOCK, top);
     ring_release(ring, hold + wave_in_block);
     Q = pt_select(dec, Q, pt_identity());
@@ -976,6 +1006,86 @@ ZC_KERNEL void k_ris_mul_base_compress(const u64* k, uint8_t* out, const u32* ta
     const pt Q = base_mul(table, sdig + tid, ZC_BLOCK, top);
     fe_to_words256(w, ris_compress(Q));
     if (valid) store_words256(out + 32 * i, w);
+}
+
+// ---- fixed-base w-NAF over the odd multiples of the basepoint (third algorithm) -------------
+// window_naf_mul (edwards.rs:155-171): Q = identity; for i from the top digit down { Q = 2Q; d = wNAF_w(k)[i];
+// d > 0: Q += T[d]; d < 0: Q -= T[|d|] } over BASEPOINT_ODD_MULTIPLES_TABLE (constants.rs:216-972: entry 0 = identity,
+// entry j = (2j - 1) B, 125 odd multiples).  The reference indexes the table with the digit itself and reads the digits
+// 249..0 only (its test is commented out, :1619-1635); this is the algorithm with both repaired: entry (|d| + 1) / 2 and
+// all 256 digits compute_window_NAF emits (scalar.rs:396-415, the loop literally -- naf_step above), so that the result
+// is (sum_i d_i 2^i) B = k B for every canonical scalar.  ONE launch: the digits of a lane sit in LDS (256 bytes per
+// lane), the table is rebuilt on the device as 125 cached AFFINE records (16 KB, L2-resident; checked entry by entry
+// against the reference's table in the GPU tier), every step is a dedicated doubling and a 7-multiplication mixed
+// addition under the lanes' digit mask.  Same group element as `&BASEPOINT * &k` and as the comb (zc_ed_mul_base) --
+// the comb (33 additions, no doublings) stays the fast answer; this one is the reference's named algorithm.
+constexpr int ZC_ODD_ENTRIES = 125;
+ZC_KERNEL void k_odd_table_build(u32* table)                 // lane j: (2j + 1) B, Z = 1, cached form
+{
+    const int j = threadIdx.x;
+    if (j >= ZC_ODD_ENTRIES) return;
+    pt B;
+    B.X = fe_const<FP>(ModP::BASE_X_M);
+    B.Y = fe_const<FP>(ModP::BASE_Y_M);
+    B.Z = fe_one_m<FP>();
+    B.T = fe_const<FP>(ModP::BASE_T_M);
+    const pt B2 = pt_add(B, B);
+    pt P = B;
+    for (int a = 0; a < ZC_ODD_ENTRIES - 1; a++) {
+        const pt s = pt_add(P, B2);
+        P = pt_select(a < j, s, P);
+    }
+    const fe zi = fp_invert(P.Z);
+    pt A;
+    A.X = fp_mul(P.X, zi);
+    A.Y = fp_mul(P.Y, zi);
+    A.Z = fe_one_m<FP>();
+    A.T = fp_mul(A.X, A.Y);
+    niels_store(table + 32 * j, niels_from_pt(A));
+}
+#ifdef ZC_TEST_HOOKS
+// test build only: the cached records back as points (4x : 4y : 4 : 4xy), to be compared with the reference's table
+ZC_KERNEL void k_test_odd_table_dump(const u32* table, u64* out)
+{
+    const int j = threadIdx.x;
+    if (j >= ZC_ODD_ENTRIES) return;
+    const niels c = niels_load(table + 32 * j);
+    const fe two = fe_add(fe_one_m<FP>(), fe_one_m<FP>());
+    pt P;
+    P.X = fp_mul(fp_sub(c.ypx, c.ymx), two);
+    P.Y = fp_mul(fe_add(c.ypx, c.ymx), two);
+    P.Z = fp_mul(two, two);
+    P.T = fp_sub(fp_mul(c.ypx, c.ypx), fp_mul(c.ymx, c.ymx));
+    pt_store(out + 20 * j, P);
+}
+#endif
+ZC_KERNEL_2W void k_ed_mul_base_wnaf(const u64* k, u32 width, u64* out, const u32* table, size_t n)
+{
+    __shared__ int8_t sdig[256 * ZC_BLOCK];                   // digit i of lane t: sdig[i * ZC_BLOCK + t]
+    const int tid = threadIdx.x;
+    const size_t i = gid();
+    const bool valid = i < n;
+    u64 kk[5], m[5];
+    load5(kk, k + 5 * (valid ? i : 0));
+    limbs52_of_modulus<ModL>(m);
+    int top = -1;
+    for (int d = 0; d < 256; d++) {
+        const int ki = naf_step(kk, m, width);
+        sdig[d * ZC_BLOCK + tid] = (int8_t)ki;
+        if (ki != 0) top = d;
+    }
+    if (!valid) top = -1;
+    top = wave_max_small(top);
+    pt Q = pt_identity();
+    for (int d = top; d >= 0; d--) {
+        if (d != top) Q = pt_double_fast<true>(Q);          // doubling the identity changes nothing: the leading one is skipped
+        const int ki = sdig[d * ZC_BLOCK + tid];
+        const int mag = ki < 0 ? -ki : ki;
+        niels c = niels_identity();
+        if (mag != 0) c = niels_load(table + 32 * ((mag - 1) >> 1));                 // |d| = 2j - 1  ->  record j - 1
+        Q = pt_add_cached<false, true>(Q, niels_cond_neg(ki < 0, c));             // table records and the identity have z = 1
+    }
+    if (valid) pt_store(out + 20 * i, Q);
 }
 
 // ltr_bin_mul (MODE 1) / binary_naf_mul (MODE 2): limbs identical to the reference's variants

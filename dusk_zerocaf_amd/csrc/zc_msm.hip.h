@@ -50,10 +50,6 @@ namespace zc {
 // 16: 1.17 / 1.55 / 2.77 / 4.42 / 24.40, 32: 1.30 / 1.68 / 2.93 / 4.56 / 24.05.
 inline int msm_segment_buckets(size_t nbuckets)
 {
-    if (const char* e = getenv("ZC_MSM_SEG")) {                // tuning: 2, 4, 8, ... (a power of two)
-        const int f = atoi(e);
-        if (f >= 2 && f <= 256 && (f & (f - 1)) == 0) return f;
-    }
     return nbuckets <= ((size_t)1 << 18) ? 8 : nbuckets >= ((size_t)1 << 21) ? 32 : 16;
 }
 constexpr int MSM_SCALAR_BITS = 261;   // 260-bit limb patterns + the carry of the signed recoding

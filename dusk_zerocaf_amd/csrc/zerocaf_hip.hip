@@ -44,8 +44,73 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 constexpr int MAX_ARGS = 6;
 
+// Tuning knobs.  Read from the environment ONCE, when a context is created, and kept
+// with the context: a process can hold contexts with different settings side by side (which is how the GPU test
+// tier runs every selectable kernel path against the oracle), and no call path touches getenv afterwards.
+// 0 / -1 = "not set": the library's own choice applies.
+struct Tuning {
+    long host_chunks = 0;            // ZC_HOST_CHUNKS=k: host batches move in k chunks
+    bool balance_global = false;     // ZC_BALANCE=global: batch-wide cost-sorted permutation for the block-shaped strict kernels
+    bool sched_block = false;        // ZC_SCHED=block: one workgroup per 256 elements instead of persistent waves
+    unsigned ring_slots = 0;         // ZC_RING_SLOTS=k (1..512): wave slots per XCD of the windowed core's table ring
+    bool ristretto_strict = false;   // ZC_RISTRETTO_STRICT=1: config-4 round trip on the reference's formula sequence
+    long inv_chunk = 0;              // ZC_INV_CHUNK=c (1..64): elements per lane sharing one inversion
+    int jacobi_rounds = -1;          // ZC_JACOBI_ROUNDS=r (0..200): rounds before legendre_symbol falls back to the power
+    int msm_window = 0;              // ZC_MSM_WINDOW=c
+    int msm_sort_packed = -1;        // ZC_MSM_SORT_PACKED=0/1
+    int msm_sort_big = -1;           // ZC_MSM_SORT_BIG=0/1
+    long msm_sort_g = 0;             // ZC_MSM_SORT_G=g (1..64)
+    int msm_affine = -1;             // ZC_MSM_AFFINE=0/1
+    int msm_run = 0;                 // ZC_MSM_RUN=T (4..4096)
+    int msm_run_edges = 0;           // ZC_MSM_RUN_EDGES=T (4..4096, even)
+    int msm_fork = -1;               // ZC_MSM_FORK=0/1
+    int msm_affine_chunk = 0;        // ZC_MSM_AFFINE_CHUNK=c (1..64)
+    int msm_seg = 0;                 // ZC_MSM_SEG=s (power of two, 2..256)
+#ifdef ZC_TEST_HOOKS
+    bool test_ring_poison = false;   // ZC_TEST_RING_POISON: pretend a wave of every windowed-core launch gave up
+    unsigned test_ring_spins = 0;    // ZC_TEST_RING_SPINS=b: waves give up after 2^b polls (default 22, about 4 s)
+#endif
+};
+inline long env_long(const char* name, long lo, long hi, long unset)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return unset;
+    const long v = atol(e);
+    return v >= lo && v <= hi ? v : unset;
+}
+Tuning tuning_from_env()
+{
+    Tuning t;
+    t.host_chunks = env_long("ZC_HOST_CHUNKS", 1, 1 << 20, 0);
+    if (const char* e = getenv("ZC_BALANCE")) t.balance_global = std::string(e) == "global";
+    if (const char* e = getenv("ZC_SCHED")) t.sched_block = std::string(e) == "block";
+    t.ring_slots = (unsigned)env_long("ZC_RING_SLOTS", 1, 512, 0);
+    t.ristretto_strict = env_long("ZC_RISTRETTO_STRICT", 0, 1 << 30, 0) != 0;
+    t.inv_chunk = env_long("ZC_INV_CHUNK", 1, 64, 0);
+    t.jacobi_rounds = (int)env_long("ZC_JACOBI_ROUNDS", 0, 200, -1);
+    t.msm_window = (int)env_long("ZC_MSM_WINDOW", 1, 64, 0);
+    t.msm_sort_packed = (int)env_long("ZC_MSM_SORT_PACKED", 0, 1 << 30, -1);
+    t.msm_sort_big = (int)env_long("ZC_MSM_SORT_BIG", 0, 1 << 30, -1);
+    t.msm_sort_g = env_long("ZC_MSM_SORT_G", 1, 64, 0);
+    t.msm_affine = (int)env_long("ZC_MSM_AFFINE", 0, 1 << 30, -1);
+    t.msm_run = (int)env_long("ZC_MSM_RUN", 4, 4096, 0);
+    t.msm_run_edges = (int)env_long("ZC_MSM_RUN_EDGES", 4, 4096, 0);
+    t.msm_fork = (int)env_long("ZC_MSM_FORK", 0, 1 << 30, -1);
+    t.msm_affine_chunk = (int)env_long("ZC_MSM_AFFINE_CHUNK", 1, 64, 0);
+    {
+        const long f = env_long("ZC_MSM_SEG", 2, 256, 0);
+        if (f && (f & (f - 1)) == 0) t.msm_seg = (int)f;
+    }
+#ifdef ZC_TEST_HOOKS
+    t.test_ring_poison = getenv("ZC_TEST_RING_POISON") != nullptr;
+    t.test_ring_spins = (unsigned)env_long("ZC_TEST_RING_SPINS", 1, 30, 0);
+#endif
+    return t;
+}
+
 struct DevState {
     int device = 0;
+    Tuning tune;                        // the context's knobs (a copy per device slot)
     int cus = 256;                      // compute units (multiProcessorCount)
     hipStream_t stream = nullptr;       // owned
     hipStream_t borrowed = nullptr;     // set by zc_ctx_set_stream (device 0 only)
@@ -63,11 +128,13 @@ struct DevState {
     size_t msm_bytes = 0;
     void* fast = nullptr;               // windowed-core tables: ring of wave slots, 256 MB (zc_kernels.hip.h)
     size_t fast_bytes = 0;
-    void* ring = nullptr;               // tickets and slot flags of the table ring (+ its error word)
+    void* ring = nullptr;               // tickets and slot flags of the table ring (+ the device address of the error word)
     size_t ring_bytes = 0;
-    bool ring_used = false;             // a windowed-core launch since the error word was last read
+    volatile zc::u32* ring_err = nullptr;   // the ring's error word: pinned host memory, written by a wave that gave up
     void* base_table = nullptr;         // comb table of the basepoint: 33 x 128 cached affine points
     size_t base_bytes = 0;
+    void* odd_table = nullptr;          // (2j - 1) B, j = 1..125, cached affine: the w-NAF's odd multiples
+    size_t odd_bytes = 0;
     void* part = nullptr;               // MSM exchange: gathered per-rank / per-device partials + the folded result
     size_t part_bytes = 0;
     hipEvent_t ev_order = nullptr;      // orders work across a stream switch / across devices
@@ -152,10 +219,8 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + zc::ZC_BLOCK - 1) / 
 // calling thread, so chunking them buys no overlap. ZC_HOST_CHUNKS=k forces k chunks.
 constexpr size_t CHUNK_ROUND = (size_t)1 << 17;
 constexpr size_t MAX_CHUNKS = 4096;
-inline size_t host_chunk_elems(size_t cnt, bool heavy)
+inline size_t host_chunk_elems(size_t cnt, bool heavy, long forced)
 {
-    const char* e = getenv("ZC_HOST_CHUNKS");
-    const long forced = e ? atol(e) : 0L;
     size_t chunk = cnt;
     if (forced > 0)
         chunk = (cnt + forced - 1) / forced;
@@ -200,6 +265,7 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bo
         for (auto& d : ctx->devs)
             if (d.device == dev_of_ptrs) ds = &d;
         if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+        if (int rc = ring_check(*ds)) return rc;            // an asynchronous failure of an earlier call surfaces here
         HIP_TRY(hipSetDevice(ds->device));
         void* dptr[MAX_ARGS];
         for (int a = 0; a < nargs; a++) dptr[a] = const_cast<void*>(args[a].ptr);
@@ -220,10 +286,11 @@ int run_batched(zc_ctx* ctx, Arg* args, int nargs, size_t n, Launch&& launch, bo
         const size_t lo = di * per, hi = std::min(n, lo + per);
         if (lo >= hi) return ZC_OK;
         const size_t total = hi - lo;
-        const size_t chunk = host_chunk_elems(total, heavy);
+        const size_t chunk = host_chunk_elems(total, heavy, ctx->devs[di].tune.host_chunks);
         const size_t nchunks = (total + chunk - 1) / chunk;
         DevState& ds = ctx->devs[di];
         auto body = [&]() -> int {
+            if (int rc0 = ring_check(ds)) return rc0;       // an asynchronous failure of an earlier call surfaces here
             HIP_TRY(hipSetDevice(ds.device));
             void* base[MAX_ARGS] = {};
             for (int a = 0; a < nargs; a++) {
@@ -343,15 +410,10 @@ int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_
 // ZC_BALANCE=global selects it; the default is the in-kernel block-local ranking, which keeps
 // HBM traffic algorithmic (a batch-wide permutation turns record reads into cache-line gathers).
 constexpr size_t BALANCE_MIN_N = 1 << 14;
-inline bool global_balance()
-{
-    static const bool g = [] { const char* e = getenv("ZC_BALANCE"); return e && std::string(e) == "global"; }();
-    return g;
-}
 constexpr size_t BAL_COUNTERS = 64;                       // u32 work counters of the persistent kernels, after the bins
 const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt, bool force = false, zc::u32** counter = nullptr)
 {
-    if ((!force && !global_balance()) || cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
+    if ((!force && !D.tune.balance_global) || cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
     const size_t need = (zc::ZC_COST_BINS + BAL_COUNTERS + cnt) * sizeof(zc::u32);
     if (ensure(&D.bal, &D.bal_bytes, need) != ZC_OK) return nullptr;
     zc::u32* hist = (zc::u32*)D.bal;
@@ -366,11 +428,6 @@ const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt, bool force =
 // Strict scalar-mul batches from this size on run on persistent waves over the cost-sorted
 // permutation (k_ed_scalar_mul_pw); ZC_SCHED=block keeps one workgroup per 256 elements.
 constexpr size_t PW_MIN_ELEMS = (size_t)1 << 17;
-inline bool persistent_waves()
-{
-    static const bool on = [] { const char* e = getenv("ZC_SCHED"); return !(e && std::string(e) == "block"); }();
-    return on;
-}
 
 // Launches of at most one workgroup per CU keep a single wave on every SIMD; a lone wave cannot
 // hide the latency of the column-ordered multiplier's serial chain, so those launches run the
@@ -390,56 +447,61 @@ inline strict_kernel_t strict_kernel_for(size_t cnt)
 // launch(table, ring_state, slots_per_xcd, offset, count).  ZC_RING_SLOTS=k (1..512) shrinks the ring so that
 // waves really wait for one another (tests; the default leaves more slots than waves fit an XCD).
 constexpr size_t FAST_MAX_LAUNCH = (size_t)1 << 31;
-inline zc::u32 ring_slots()
-{
-    if (const char* e = getenv("ZC_RING_SLOTS")) {
-        const long v = atol(e);
-        if (v >= 1 && v <= (long)zc::RING_SLOTS) return (zc::u32)v;
-    }
-    return zc::RING_SLOTS;
-}
 template <class L>
 int fast_ring(DevState& D, size_t cnt, L&& launch)
 {
     int rc = ensure(&D.fast, &D.fast_bytes, zc::RING_TABLE_BYTES);
     if (rc) return rc;
     if (!D.ring) {
+        // The error word lives in pinned HOST memory the device can write (a wave that gives up stores through the
+        // address parked behind the ring state): the host reads it at every entry point without any synchronisation.
+        if (!D.ring_err) {
+            void* h = nullptr;
+            hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+            if (e != hipSuccess) return fail(ZC_ERR_NOMEM, "hipHostMalloc(ring error word)", e);
+            D.ring_err = (volatile zc::u32*)h;
+            *D.ring_err = 0;
+        }
         rc = ensure(&D.ring, &D.ring_bytes, zc::RING_ALLOC_WORDS * sizeof(zc::u32));
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(D.ring, 0, zc::RING_ALLOC_WORDS * sizeof(zc::u32), D.s()));     // the error word starts clear
+        void* dev_view = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dev_view, (void*)D.ring_err, 0));
+        const u64 addr = (u64)(uintptr_t)dev_view;
+        HIP_TRY(hipMemcpy((zc::u32*)D.ring + zc::RING_ERR_WORD, &addr, sizeof addr, hipMemcpyHostToDevice));   // once per device slot
     }
     // a launch hands out fewer than 2^19 generations of its slots (the 19-bit field of the word ring_acquire parks)
-    const zc::u32 slots = ring_slots();
+    const zc::u32 slots = D.tune.ring_slots ? (zc::u32)D.tune.ring_slots : zc::RING_SLOTS;
+    zc::u32 slots_arg = slots;
+#ifdef ZC_TEST_HOOKS
+    slots_arg |= (zc::u32)D.tune.test_ring_spins << 16;      // test build: the kernels take their spin limit from the upper half
+#endif
     const size_t max_launch = std::min(FAST_MAX_LAUNCH, (size_t)slots << 24);
     for (size_t off = 0; off < cnt; off += max_launch) {
         HIP_TRY(hipMemsetAsync(D.ring, 0, zc::RING_STATE_WORDS * sizeof(zc::u32), D.s()));
-        launch((zc::u32*)D.fast, (zc::u32*)D.ring, slots, off, std::min(max_launch, cnt - off));
+        launch((zc::u32*)D.fast, (zc::u32*)D.ring, slots_arg, off, std::min(max_launch, cnt - off));
     }
-    D.ring_used = true;
-    if (getenv("ZC_TEST_RING_POISON"))                         // tests: pretend a wave gave up (exercises ring_check's report-and-recover path)
-        HIP_TRY(hipMemsetAsync((zc::u32*)D.ring + zc::RING_ERR_WORD, 1, 1, D.s()));
+#ifdef ZC_TEST_HOOKS
+    if (D.tune.test_ring_poison) *D.ring_err = 1;            // pretend a wave gave up (exercises the report-and-recover path)
+#endif
     return ZC_OK;
 }
-// After a synchronisation of D's stream: did a wave of a windowed-core launch give up waiting for its table slot
-// (zc_kernels.hip.h: ring_acquire)?  Reads and clears the error word; the context stays usable.
+// Did a wave of an earlier windowed-core launch on this device give up waiting for its table slot (zc_kernels.hip.h:
+// ring_acquire)?  Such a wave writes poison outputs (limbs / bytes of all ones, ok = 0) and sets the error word in
+// host memory; every entry point that touches the device looks at it first, and so does everything that synchronises.
+// Reported once (ZC_ERR_HIP), then cleared: the context stays usable.
 int ring_check(DevState& D)
 {
-    if (!D.ring_used || !D.ring) return ZC_OK;
-    D.ring_used = false;
-    zc::u32 err = 0;
-    zc::u32* word = (zc::u32*)D.ring + zc::RING_ERR_WORD;
-    HIP_TRY(hipMemcpyAsync(&err, word, sizeof(err), hipMemcpyDeviceToHost, D.s()));
-    HIP_TRY(hipStreamSynchronize(D.s()));
-    if (!err) return ZC_OK;
-    HIP_TRY(hipMemsetAsync(word, 0, sizeof(err), D.s()));
-    return fail(ZC_ERR_HIP, "windowed core: a wave timed out waiting for its table slot; the outputs of the last windowed-core calls on this device are not valid");
+    if (!D.ring_err || *D.ring_err == 0) return ZC_OK;
+    *D.ring_err = 0;
+    return fail(ZC_ERR_HIP, "windowed core: a wave timed out waiting for its table slot; the rows it owned hold poison (all ones) -- "
+                            "the outputs of the last windowed-core calls on this device are not valid");
 }
 int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n)
 {
     REQUIRE(p); REQUIRE(k); REQUIRE(out);
     Arg args[3] = {in_arg(p, 160), in_arg(k, 40), out_arg(out, 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        if (cnt >= PW_MIN_ELEMS && persistent_waves()) {
+        if (cnt >= PW_MIN_ELEMS && !D.tune.sched_block) {
             zc::u32* counter = nullptr;
             if (const zc::u32* perm = balance_index(D, (const u64*)d[1], cnt, true, &counter)) {
                 hipLaunchKernelGGL(zc::k_ed_scalar_mul_pw, dim3((unsigned)(3 * D.cus)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1],
@@ -500,8 +562,8 @@ struct Carver {
 // Window width: signed digits put 2^(c-1) buckets in a window; c = log2(n) - 4 keeps about 32
 // points per bucket, where the bucket reduction (~3.7 additions per bucket) stays well below the
 // bucket sums (1 addition per point and window); measured flat within 3 % for c +- 1 up to 2^18 and at 2^21,
-// and for c = 18..21 at 2^24 (tools/quick_bench.py msmsweep).  ZC_MSM_WINDOW=c overrides (tests, tuning).
-int msm_window_bits(size_t cnt)
+// and for c = 18..21 at 2^24 (tools/quick_bench.py msmsweep).  ZC_MSM_WINDOW=c overrides (tests, tuning; read at context creation like every knob).
+int msm_window_bits(size_t cnt, const Tuning& tune)
 {
     int c = 0;
     while (((size_t)1 << (c + 1)) <= cnt) c++;
@@ -509,10 +571,7 @@ int msm_window_bits(size_t cnt)
     if (c == 15 || c == 16) c = 17;                       // 2^19, 2^20 pairs: 16 windows of 17 bits beat 18 of 15 / 17 of 16 (measured -4 %)
     if (c < zc::MSM_MIN_C) c = zc::MSM_MIN_C;
     if (c > 18) c = 18;                                   // beyond: no faster (2^24 pairs: c = 18 / 19 / 20: 21.4 / 21.9 / 22.9 ms), bucket memory doubles per step
-    if (const char* e = getenv("ZC_MSM_WINDOW")) {
-        const int f = atoi(e);
-        if (f >= zc::MSM_MIN_C && f <= zc::MSM_MAX_C) c = f;
-    }
+    if (tune.msm_window >= zc::MSM_MIN_C && tune.msm_window <= zc::MSM_MAX_C) c = tune.msm_window;
     return c;
 }
 
@@ -528,7 +587,7 @@ struct MsmSortPlan {
     zc::msm_sort_pass pass[4];
     size_t table_words = 0;                                   // largest table, padded to whole scan blocks
 };
-MsmSortPlan msm_sort_plan(size_t n, int c, int W)
+MsmSortPlan msm_sort_plan(size_t n, int c, int W, const Tuning& tune)
 {
     MsmSortPlan pl;
     const int B = c - 1;
@@ -536,18 +595,14 @@ MsmSortPlan msm_sort_plan(size_t n, int c, int W)
     // two-word records of large batches: tiles of 8192 keys (ZC_MSM_SORT_BIG=0/1 forces the choice)
     int idx_bits = 1;
     while (((size_t)1 << idx_bits) < n) idx_bits++;
-    const char* pe = getenv("ZC_MSM_SORT_PACKED");
-    pl.packed = pl.passes == 2 && 1 + (B - (B + 1) / 2) + 1 + idx_bits <= 32 && !(pe && atoi(pe) == 0);
+    pl.packed = pl.passes == 2 && 1 + (B - (B + 1) / 2) + 1 + idx_bits <= 32 && tune.msm_sort_packed != 0;
     pl.big = !pl.packed && n >= ((size_t)1 << 22);
-    if (const char* e = getenv("ZC_MSM_SORT_BIG")) pl.big = !pl.packed && atoi(e) != 0;
+    if (tune.msm_sort_big >= 0) pl.big = !pl.packed && tune.msm_sort_big != 0;
     const size_t tile = (size_t)zc::ZC_BLOCK * (pl.big ? zc::MSM_SORT_KPT_BIG : zc::MSM_SORT_KPT);
     const size_t ntiles = (n + tile - 1) / tile;
     size_t G = ntiles / 128;
     G = std::max<size_t>(1, std::min<size_t>(16, G));
-    if (const char* e = getenv("ZC_MSM_SORT_G")) {
-        const long f = atol(e);
-        if (f >= 1 && f <= 64) G = (size_t)f;
-    }
+    if (tune.msm_sort_g) G = (size_t)tune.msm_sort_g;
     const size_t ncols = (ntiles + G - 1) / G;
     int shift = 0;
     for (int i = 0; i < pl.passes; i++) {
@@ -606,10 +661,45 @@ int msm_sort(DevState& D, const MsmSortPlan& pl, const zc::u32* digits, uint2* b
 // normalisation costs one division-step inversion per lane, which small batches cannot amortise.
 // ZC_MSM_AFFINE=0/1 forces the choice (tests, A/B).
 constexpr size_t MSM_AFFINE_MIN_N = (size_t)1 << 17;
-inline bool msm_affine(size_t cnt)
+inline bool msm_affine(size_t cnt, const Tuning& tune)
 {
-    if (const char* e = getenv("ZC_MSM_AFFINE")) return atoi(e) != 0;
+    if (tune.msm_affine >= 0) return tune.msm_affine != 0;
     return cnt >= MSM_AFFINE_MIN_N;
+}
+
+// Everything the pipeline derives from the shard size and the knobs, in one place (also what zc_msm_plan reports).
+struct MsmPlan {
+    bool buckets = false;          // false: below MSM_BUCKET_MIN_N -- n scalar multiplications + pairwise folds
+    int c = 0, W = 0;              // window bits, windows
+    bool affine = false;           // 96-byte affine records + 7-multiplication additions (else 128-byte projective, 8)
+    int T = 0, TE = 0;             // run lengths of the segmented reduction: level 0, deeper levels
+    int seg = 0;                   // buckets per reduction segment
+    size_t m = 0, nb = 0, nseg = 0;   // list entries (n W), buckets, segments
+    MsmSortPlan sort;
+};
+MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
+{
+    MsmPlan p;
+    if (cnt < MSM_BUCKET_MIN_N) return p;
+    p.buckets = true;
+    p.c = msm_window_bits(cnt, tune);
+    p.W = (zc::MSM_SCALAR_BITS + p.c - 1) / p.c;          // any 260-bit pattern + the recoding carry
+    p.m = cnt * (size_t)p.W;
+    p.nb = (size_t)p.W << (p.c - 1);                      // buckets (digit magnitudes 1 .. 2^(c-1) per window)
+    p.seg = tune.msm_seg ? tune.msm_seg : zc::msm_segment_buckets(p.nb);
+    p.nseg = p.nb / (size_t)p.seg;
+    p.sort = msm_sort_plan(cnt, p.c, p.W, tune);
+    p.affine = msm_affine(cnt, tune) && points_aligned16;  // the normalisation moves the point records with 16-byte loads
+    // run length of the segmented reduction: 128 entries per lane, fewer when the list is short (keep
+    // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
+    // levels.  Measured (tools/quick_bench.py, ZC_MSM_RUN / ZC_MSM_RUN_EDGES): 2^20 pairs T = 32 / 128 / 256:
+    // 2.90 / 2.83 / 3.12 ms; 2^21: 4.67 / 4.48 / 4.52; edge runs of 8 / 16 / 32: 2^21 4.44 / 4.53 / 4.63 ms.
+    // Round 3, 2^24 pairs (2^27.9 entries): T = 128 / 256: 21.94 / 21.53 ms -- half the edges for the deeper levels.
+    p.T = p.m >= ((size_t)1 << 27) ? 256 : (int)std::min<size_t>(128, std::max<size_t>(8, p.m >> 17));
+    p.TE = 8;                                             // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
+    if (tune.msm_run) p.T = tune.msm_run;                 // T >= 4: every level shortens the list (2 ceil(len / T) < len)
+    if (tune.msm_run_edges) p.TE = tune.msm_run_edges & ~1;
+    return p;
 }
 
 // sum_i k_i P_i of one device's shard, enqueued on D.s() without any host synchronisation;
@@ -629,39 +719,13 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         return ZC_OK;
     }
     if (cnt > 0x7FFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 31-bit point indices");
-    const int c = msm_window_bits(cnt);
-    const int W = (zc::MSM_SCALAR_BITS + c - 1) / c;      // any 260-bit pattern + the recoding carry
-    if (getenv("ZC_DEBUG_OCCUPANCY")) {
-        int a = 0, b = 0, e = 0, f = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, zc::k_msm_runs, zc::ZC_BLOCK, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, zc::k_ed_scalar_mul_pw, zc::ZC_BLOCK, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, zc::k_ris_roundtrip_mul_fast, zc::ZC_BLOCK, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, zc::k_msm_segments, zc::ZC_BLOCK, 0);
-        fprintf(stderr, "occupancy (workgroups of 256 per CU): k_msm_runs %d, k_ed_scalar_mul_pw %d, k_ris_roundtrip_mul_fast %d, k_msm_segments %d\n", a, b, e, f);
-    }
-    const size_t m = cnt * (size_t)W;
+    const Tuning& tune = D.tune;
+    const MsmPlan mp = msm_plan(cnt, aligned16(dP), tune);
+    const int c = mp.c, W = mp.W, seg = mp.seg, T = mp.T, TE = mp.TE;
+    const size_t m = mp.m, nb = mp.nb, nseg = mp.nseg;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
-    const size_t nb = (size_t)W << (c - 1);               // buckets (digit magnitudes 1 .. 2^(c-1) per window)
-    const int seg = zc::msm_segment_buckets(nb);
-    const size_t nseg = nb / (size_t)seg;
-    const MsmSortPlan plan = msm_sort_plan(cnt, c, W);
-    const bool affine = msm_affine(cnt) && aligned16(dP);   // the normalisation moves the point records with 16-byte loads
-
-    // run length of the segmented reduction: 128 entries per lane, fewer when the list is short (keep
-    // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
-    // levels.  Measured (tools/quick_bench.py, ZC_MSM_RUN / ZC_MSM_RUN_EDGES): 2^20 pairs T = 32 / 128 / 256:
-    // 2.90 / 2.83 / 3.12 ms; 2^21: 4.67 / 4.48 / 4.52; edge runs of 8 / 16 / 32: 2^21 4.44 / 4.53 / 4.63 ms.
-    // Round 3, 2^24 pairs (2^27.9 entries): T = 128 / 256: 21.94 / 21.53 ms -- half the edges for the deeper levels.
-    int T = m >= ((size_t)1 << 27) ? 256 : (int)std::min<size_t>(128, std::max<size_t>(8, m >> 17));
-    int TE = 8;                                           // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
-    if (const char* e = getenv("ZC_MSM_RUN")) {
-        const int f = atoi(e);
-        if (f >= 4 && f <= 4096) T = f;                   // T >= 4: every level shortens the list (2 ceil(len / T) < len)
-    }
-    if (const char* e = getenv("ZC_MSM_RUN_EDGES")) {
-        const int f = atoi(e);
-        if (f >= 4 && f <= 4096) TE = f & ~1;
-    }
+    const MsmSortPlan& plan = mp.sort;
+    const bool affine = mp.affine;
     const size_t nl0 = (m + T - 1) / T;                   // lanes (= runs) of level 0
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
@@ -689,8 +753,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         // 3.89 -> 3.80 ms (the sort's kernels slow down beside it, the pair still ends 60-90 us earlier); at 2^24 both sides are
         // bandwidth-bound for milliseconds and the pair ends no earlier (21.5 vs 21.7 ms), so large shards stay in line.
         // ZC_MSM_FORK=0/1 forces the choice.
-        static const int fork_env = [] { const char* e = getenv("ZC_MSM_FORK"); return e ? atoi(e) : -1; }();
-        const bool fork = fork_env >= 0 ? fork_env != 0 : cnt < ((size_t)1 << 23);
+        const bool fork = tune.msm_fork >= 0 ? tune.msm_fork != 0 : cnt < ((size_t)1 << 23);
         hipStream_t ps = D.s();
         if (fork && D.aux) {
             HIP_TRY(hipEventRecord(D.ev_fork, D.s()));
@@ -701,10 +764,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             // points per lane of the normalisation: enough lanes for two to four waves per SIMD, enough points per
             // lane to amortise its inversion (ZC_MSM_AFFINE_CHUNK overrides)
             int ac = (int)std::min<size_t>(16, std::max<size_t>(1, cnt >> 18));
-            if (const char* e = getenv("ZC_MSM_AFFINE_CHUNK")) {
-                const int f = atoi(e);
-                if (f >= 1 && f <= 64) ac = f;
-            }
+            if (tune.msm_affine_chunk) ac = tune.msm_affine_chunk;
             const size_t lanes = (cnt + ac - 1) / ac;            // lane g owns points g, g + stride, ...: stride = the launch's lanes
             hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt, ac);
         } else {
@@ -881,9 +941,11 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         }
     }
     zc_ctx* ctx = new zc_ctx();
+    const Tuning tune = tuning_from_env();                   // the only place the library reads its knobs
     for (int id : ids) {
         DevState ds;
         ds.device = id;
+        ds.tune = tune;
         hipError_t e = hipSetDevice(id);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&ds.cus, hipDeviceAttributeMultiprocessorCount, id);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking);
@@ -928,7 +990,9 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.msm) (void)hipFree(ds.msm);
         if (ds.fast) (void)hipFree(ds.fast);
         if (ds.ring) (void)hipFree(ds.ring);
+        if (ds.ring_err) (void)hipHostFree((void*)ds.ring_err);
         if (ds.base_table) (void)hipFree(ds.base_table);
+        if (ds.odd_table) (void)hipFree(ds.odd_table);
         for (hipEvent_t e : ds.ev) (void)hipEventDestroy(e);
         if (ds.copy_in) (void)hipStreamDestroy(ds.copy_in);
         if (ds.copy_out) (void)hipStreamDestroy(ds.copy_out);
@@ -996,12 +1060,9 @@ int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return u
 // element + one inversion per lane).  c = cnt / INV_LANES_TARGET keeps that many lanes busy, capped at 64;
 // below 2 the kernels take one element per lane.  ZC_INV_CHUNK=c overrides (tuning, tests).
 constexpr size_t INV_LANES_TARGET = 65536;
-inline size_t inv_chunk(size_t cnt)
+inline size_t inv_chunk(size_t cnt, const Tuning& tune)
 {
-    if (const char* e = getenv("ZC_INV_CHUNK")) {
-        const long v = atol(e);
-        if (v >= 1 && v <= 64) return (size_t)v;
-    }
+    if (tune.inv_chunk) return (size_t)tune.inv_chunk;
     size_t c = cnt / INV_LANES_TARGET;
     return c > 32 ? 32 : c;
 }
@@ -1011,7 +1072,7 @@ int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, siz
     REQUIRE(a); REQUIRE(out);
     Arg args[3] = {in_arg(a, 40), out_arg(out, 40), out_arg(ok, 1)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        const size_t c = inv_chunk(cnt);
+        const size_t c = inv_chunk(cnt, D.tune);
         if (c < 2 || d[0] == d[1]) {                       // tiny batch or in-place: one element per lane
             hipLaunchKernelGGL(zc::k_fe_invert, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
         } else {
@@ -1025,7 +1086,7 @@ int zc_fe_div(zc_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, 
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     Arg args[4] = {in_arg(a, 40), in_arg(b, 40), out_arg(out, 40), out_arg(ok, 1)};
     return run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
-        const size_t c = inv_chunk(cnt);
+        const size_t c = inv_chunk(cnt, D.tune);
         if (c < 2 || d[2] == d[0] || d[2] == d[1]) {
             hipLaunchKernelGGL(zc::k_fe_div, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
         } else {
@@ -1048,14 +1109,9 @@ static int fe_flag_op(zc_ctx* ctx, void (*k)(const u64*, uint8_t*, size_t), cons
 int zc_fe_legendre_symbol(zc_ctx* ctx, const uint64_t* a, uint8_t* out, size_t n)
 {
     REQUIRE(a); REQUIRE(out);
-    int rounds = zc::JACOBI_MAX_ROUNDS;
-    if (const char* e = getenv("ZC_JACOBI_ROUNDS")) {
-        const int f = atoi(e);
-        if (f >= 0 && f <= 200) rounds = f;
-    }
     Arg args[2] = {in_arg(a, 40), out_arg(out, 1)};
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
-        hipLaunchKernelGGL(zc::k_fe_legendre, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt, rounds);
+        hipLaunchKernelGGL(zc::k_fe_legendre, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (uint8_t*)d[1], cnt, D.tune.jacobi_rounds >= 0 ? D.tune.jacobi_rounds : zc::JACOBI_MAX_ROUNDS);
     });
 }
 int zc_fe_is_positive(zc_ctx* c, const uint64_t* a, uint8_t* o, size_t n) { return fe_flag_op(c, zc::k_fe_is_positive, a, o, n); }
@@ -1186,7 +1242,7 @@ int zc_ed_to_affine(zc_ctx* ctx, const uint64_t* p, uint64_t* xy, uint8_t* ok, s
     REQUIRE(p); REQUIRE(xy);
     Arg args[3] = {in_arg(p, 160), out_arg(xy, 80), out_arg(ok, 1)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        const size_t c = inv_chunk(cnt);
+        const size_t c = inv_chunk(cnt, D.tune);
         if (c < 2) {
             hipLaunchKernelGGL(zc::k_ed_to_affine, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
         } else {
@@ -1251,10 +1307,9 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
     Arg args[4] = {in_arg(in32, 32), in_arg(k, 40), out_arg(out32, 32), out_arg(ok, 1)};
     // The boundary is encodings in / encodings out, which depend only on the group element, so
     // the fast scalar-mul core is used (ZC_RISTRETTO_STRICT=1 runs the reference formula sequence).
-    static const bool strict = [] { const char* e = getenv("ZC_RISTRETTO_STRICT"); return e && atoi(e) != 0; }();
     int inner = ZC_OK;
     int rc = run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
-        if (strict) {
+        if (D.tune.ristretto_strict) {
             const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
             hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
             return;
@@ -1383,6 +1438,24 @@ int zc_ris_mul_base_compress(zc_ctx* ctx, const uint64_t* k, uint8_t* out32, siz
     return rc ? rc : inner;
 }
 
+// window_naf_mul (src/edwards.rs:155-171) with its table indexed correctly: see k_ed_mul_base_wnaf
+int zc_ed_mul_base_wnaf(zc_ctx* ctx, const uint64_t* k, unsigned width, uint64_t* out, size_t n)
+{
+    REQUIRE(k); REQUIRE(out);
+    if (width < 2 || width > 7) return fail(ZC_ERR_BAD_ARG, "zc_ed_mul_base_wnaf: window width 2..7 (compute_window_NAF's digits are i8)");
+    Arg args[2] = {in_arg(k, 40), out_arg(out, 160)};
+    int inner = ZC_OK;
+    int rc = run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
+        if (!D.odd_table) {
+            if ((inner = ensure(&D.odd_table, &D.odd_bytes, (size_t)zc::ZC_ODD_ENTRIES * 128)) != ZC_OK) return;
+            hipLaunchKernelGGL(zc::k_odd_table_build, dim3(1), dim3(128), 0, D.s(), (zc::u32*)D.odd_table);
+        }
+        hipLaunchKernelGGL(zc::k_ed_mul_base_wnaf, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (zc::u32)width, (u64*)d[1],
+                           (const zc::u32*)D.odd_table, cnt);
+    });
+    return rc ? rc : inner;
+}
+
 // ---- MSM: sum_i k_i * P_i (not in the reference; specified as the reference's own
 // sum of `&P_i * &k_i`, src/edwards.rs:547-561 + :465-489).  Per GPU: bucket method (zc_msm.hip.h)
 // for shards of >= MSM_BUCKET_MIN_N pairs, otherwise batched scalar-mul + pairwise folds.
@@ -1487,7 +1560,9 @@ int zc_msm(zc_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t 
     return ZC_OK;
 }
 
-// Test hook, NOT part of the ABI (not in include/zerocaf_hip.h, not mirrored): the MSM's digit + sort stage alone.
+#ifdef ZC_TEST_HOOKS
+// Test hook, compiled only into libzerocaf_hip_test.so (-DZC_TEST_HOOKS), NOT part of the ABI (not in include/zerocaf_hip.h,
+// not mirrored): the MSM's digit + sort stage alone.
 // `scalars` (n x 5 u64) and `out_pairs` (n * ceil(261 / c) pairs of u32: bucket key, point index | sign << 31)
 // are DEVICE buffers of ctx's device slot 0; synchronises before returning.
 int zc_test_msm_sort(zc_ctx* ctx, const uint64_t* scalars, size_t n, int c, uint32_t* out_pairs)
@@ -1501,7 +1576,7 @@ int zc_test_msm_sort(zc_ctx* ctx, const uint64_t* scalars, size_t n, int c, uint
     const int W = (zc::MSM_SCALAR_BITS + c - 1) / c;
     const size_t m = n * (size_t)W;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_test_msm_sort: too many pairs");
-    const MsmSortPlan plan = msm_sort_plan(n, c, W);
+    const MsmSortPlan plan = msm_sort_plan(n, c, W, D.tune);
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
         zc::u32* digits = cv.take<zc::u32>(m);
@@ -1522,6 +1597,40 @@ int zc_test_msm_sort(zc_ctx* ctx, const uint64_t* scalars, size_t n, int c, uint
         HIP_TRY(hipStreamSynchronize(D.s()));
         HIP_TRY(hipGetLastError());
     }
+    return ZC_OK;
+}
+// Test hook: the w-NAF's odd-multiples table as the device built it, as 125 points in DEVICE memory of slot 0.
+int zc_test_odd_table(zc_ctx* ctx, uint64_t* out_dev_points)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(out_dev_points);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DevState& D = ctx->devs[0];
+    HIP_TRY(hipSetDevice(D.device));
+    if (!D.odd_table) {
+        int rc = ensure(&D.odd_table, &D.odd_bytes, (size_t)zc::ZC_ODD_ENTRIES * 128);
+        if (rc) return rc;
+        hipLaunchKernelGGL(zc::k_odd_table_build, dim3(1), dim3(128), 0, D.s(), (zc::u32*)D.odd_table);
+    }
+    hipLaunchKernelGGL(zc::k_test_odd_table_dump, dim3(1), dim3(128), 0, D.s(), (const zc::u32*)D.odd_table, (u64*)out_dev_points);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(D.s()));
+    return ZC_OK;
+}
+#endif  // ZC_TEST_HOOKS
+
+// What the bucket method would do for a shard of n pairs on this context (its knobs included) -- a query, no device
+// work.  A measurement aid: a roofline record counts the useful multiplications from c, W and the addition formula.
+// out8: [0] window bits c (0: below the bucket threshold, n scalar multiplications + folds), [1] windows W,
+// [2] 1 = affine 96-byte records / 7-multiplication additions, 0 = projective 128-byte / 8, [3] bytes per gathered
+// record, [4] run length T of the bucket-sum kernel, [5] buckets per reduction segment, [6] sort passes, [7] 0.
+int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out8)
+{
+    if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
+    REQUIRE(out8);
+    const MsmPlan p = msm_plan(n, points_aligned16 != 0, ctx->devs[0].tune);
+    const int32_t v[8] = {p.c, p.W, p.affine ? 1 : 0, p.buckets ? (p.affine ? 96 : 128) : 0, p.T, p.seg, p.sort.passes, 0};
+    memcpy(out8, v, sizeof v);
     return ZC_OK;
 }
 

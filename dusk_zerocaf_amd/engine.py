@@ -26,20 +26,24 @@ def _is_torch(x) -> bool:
 
 
 class Engine:
-    """One zc_ctx.  `devices=None` uses the current HIP device."""
+    """One zc_ctx.  `devices=None` = one slot on torch's current device when torch is loaded and sees a GPU,
+    otherwise on device 0.  The context reads the library's tuning knobs (ZC_* environment variables,
+    INTEGRATION.md section 6) once, here.  `lib`: another build of the same ABI (tests: the ZC_TEST_HOOKS build)."""
 
-    def __init__(self, devices=None):
-        self.lib = _lib.load()
+    def __init__(self, devices=None, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
         self.ctx = C.c_void_p()
         self._pinned_stream = False      # set_stream() was called: keep that stream
         self._last_torch_stream = {}     # device slot -> handle of the torch stream last bound to it
-        self._devices = list(devices) if devices else None      # slot i of the context = HIP device _devices[i]
-        if devices:
-            arr = (C.c_int * len(devices))(*devices)
-            rc = self.lib.zc_ctx_create(arr, len(devices), C.byref(self.ctx))
-        else:
-            rc = self.lib.zc_ctx_create(None, 0, C.byref(self.ctx))
-        _lib.check(rc, "zc_ctx_create")
+        if not devices:
+            import sys
+            torch = sys.modules.get("torch")
+            devices = [torch.cuda.current_device()] if torch is not None and torch.cuda.is_available() else [0]
+        self._devices = list(devices)    # slot i of the context = HIP device _devices[i]; always known, so the
+                                         # ownership check of _follow_torch_stream always runs
+        arr = (C.c_int * len(self._devices))(*self._devices)
+        rc = self.lib.zc_ctx_create(arr, len(self._devices), C.byref(self.ctx))
+        _lib.check(rc, "zc_ctx_create", self.lib)
 
     def close(self):
         if self.ctx:
@@ -55,14 +59,14 @@ class Engine:
     def set_stream(self, stream_handle):
         """Launch on the caller's HIP stream (handle 0 = the HIP null stream, which is what
         torch.cuda.current_stream().cuda_stream is by default)."""
-        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(stream_handle), 1), "zc_ctx_set_stream")
+        _lib.check(self.lib.zc_ctx_set_stream(self.ctx, C.c_void_p(stream_handle), 1), "zc_ctx_set_stream", self.lib)
         self._pinned_stream = True
 
     def use_own_stream(self):
         """Back to the default: host batches run on the context's own stream; calls on torch CUDA
         tensors follow torch's current stream of that device (see _follow_torch_stream)."""
-        for slot in (range(len(self._devices)) if self._devices else (0,)):
-            _lib.check(self.lib.zc_ctx_set_stream_dev(self.ctx, slot, None, 0), "zc_ctx_set_stream_dev")
+        for slot in range(len(self._devices)):
+            _lib.check(self.lib.zc_ctx_set_stream_dev(self.ctx, slot, None, 0), "zc_ctx_set_stream_dev", self.lib)
         self._pinned_stream = False
         self._last_torch_stream = {}
 
@@ -77,19 +81,17 @@ class Engine:
         if self._pinned_stream:
             return
         import torch
-        slot = 0
-        if self._devices is not None:
-            dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
-            if dev not in self._devices:
-                raise _lib.ZerocafHipError("tensor on cuda:%d, but this engine's context owns devices %s" % (dev, self._devices))
-            slot = self._devices.index(dev)
+        dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        if dev not in self._devices:
+            raise _lib.ZerocafHipError("tensor on cuda:%d, but this engine's context owns devices %s" % (dev, self._devices))
+        slot = self._devices.index(dev)
         h = torch.cuda.current_stream(t.device).cuda_stream
         if self._last_torch_stream.get(slot) != h:
-            _lib.check(self.lib.zc_ctx_set_stream_dev(self.ctx, slot, C.c_void_p(h), 1), "zc_ctx_set_stream_dev")
+            _lib.check(self.lib.zc_ctx_set_stream_dev(self.ctx, slot, C.c_void_p(h), 1), "zc_ctx_set_stream_dev", self.lib)
             self._last_torch_stream[slot] = h
 
     def synchronize(self):
-        _lib.check(self.lib.zc_ctx_synchronize(self.ctx), "zc_ctx_synchronize")
+        _lib.check(self.lib.zc_ctx_synchronize(self.ctx), "zc_ctx_synchronize", self.lib)
 
     # ------------------------------------------------------------------ helpers
     def _prep(self, x, width, dtype):
@@ -115,7 +117,7 @@ class Engine:
         return a, a.ctypes.data
 
     def _call(self, name, *args):
-        _lib.check(getattr(self.lib, name)(self.ctx, *args), name)
+        _lib.check(getattr(self.lib, name)(self.ctx, *args), name, self.lib)
 
     def _bin(self, name, a, b, w):
         a, pa, n = self._prep(a, w, np.uint64)
@@ -413,6 +415,20 @@ class Engine:
         out, po = self._alloc(k, n, 20, np.uint64)
         self._call("zc_ed_mul_base", pk, po, n)
         return out
+
+    def ed_mul_base_wnaf(self, k, width):
+        """window_naf_mul (edwards.rs:155-171) with the table indexed correctly, one launch; width 2..7."""
+        k, pk, n = self._prep(k, 5, np.uint64)
+        out, po = self._alloc(k, n, 20, np.uint64)
+        self._call("zc_ed_mul_base_wnaf", pk, int(width), po, n)
+        return out
+
+    def msm_plan(self, n, points_aligned16=True):
+        """What the bucket method would do for a shard of n pairs on this context (a query, no device work)."""
+        v = (C.c_int32 * 8)()
+        self._call("zc_msm_plan", int(n), 1 if points_aligned16 else 0, v)
+        return {"window_bits": v[0], "windows": v[1], "affine": bool(v[2]), "record_bytes": v[3], "run": v[4],
+                "segment_buckets": v[5], "sort_passes": v[6]}
 
     def ris_mul_base_compress(self, k):
         k, pk, n = self._prep(k, 5, np.uint64)

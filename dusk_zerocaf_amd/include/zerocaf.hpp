@@ -613,6 +613,23 @@ inline std::vector<EdwardsPoint> mul_base_batch(const std::vector<Scalar>& ks)
     for (size_t i = 0; i < ks.size(); i++) out[i] = EdwardsPoint::unflat(&o[20 * i]);
     return out;
 }
+// window_naf_mul (src/edwards.rs:155-171) with its table indexed correctly, one launch; width 2..7
+inline std::vector<EdwardsPoint> window_naf_mul_batch(const std::vector<Scalar>& ks, unsigned width)
+{
+    std::vector<uint64_t> k(ks.size() * 5), o(ks.size() * 20);
+    for (size_t i = 0; i < ks.size(); i++) std::memcpy(&k[5 * i], ks[i].l.data(), 40);
+    Backend::check(zc_ed_mul_base_wnaf(Backend::ctx(), k.data(), width, o.data(), ks.size()), "zc_ed_mul_base_wnaf");
+    std::vector<EdwardsPoint> out(ks.size());
+    for (size_t i = 0; i < ks.size(); i++) out[i] = EdwardsPoint::unflat(&o[20 * i]);
+    return out;
+}
+// the bucket method's plan for a shard of n pairs: {c, W, affine, record bytes, run, segment, sort passes, 0}
+inline std::array<int32_t, 8> msm_plan(size_t n, bool points_aligned16 = true)
+{
+    std::array<int32_t, 8> v{};
+    Backend::check(zc_msm_plan(Backend::ctx(), n, points_aligned16 ? 1 : 0, v.data()), "zc_msm_plan");
+    return v;
+}
 // key generation: (RISTRETTO_BASEPOINT * k).compress(), identical bytes
 inline std::vector<CompressedRistretto> ristretto_keygen_batch(const std::vector<Scalar>& ks)
 {

@@ -82,10 +82,12 @@ int zc_ctx_set_stream(zc_ctx *ctx, void *hip_stream, int external);
 /* the same for device slot `slot` (index into the `devices` array of zc_ctx_create).  A switch
  * orders everything already enqueued on the old stream before later work on the new one.       */
 int zc_ctx_set_stream_dev(zc_ctx *ctx, int slot, void *hip_stream, int external);
-/* Waits for the streams of every device slot.  Also the place where the one asynchronous error of the
- * library surfaces for callers that only pass device pointers: a wave of the windowed core (ZC_SCALAR_MUL_FAST,
- * zc_ris_roundtrip_mul) that timed out on its table slot -- a wedged device -- is reported here (and by every
- * host-pointer call, which synchronises anyway) as ZC_ERR_HIP, once; the context stays usable.               */
+/* Waits for the streams of every device slot.  The one asynchronous error of the library surfaces here AND at the
+ * start of every later entry point that touches the device (whoever synchronised the stream, the library or the
+ * caller): a wave of the windowed core (zc_ed_scalar_mul with ZC_SCALAR_MUL_FAST, zc_ris_roundtrip_mul) that timed
+ * out on its table slot -- a wedged device.  Such a wave writes POISON into the rows it owned (limbs / bytes of all
+ * ones, ok = 0) and sets an error word in pinned host memory; the call that sees the word returns ZC_ERR_HIP once
+ * and clears it; the context stays usable.  (Host-pointer calls synchronise themselves and report it directly.)   */
 int zc_ctx_synchronize(zc_ctx *ctx);
 int zc_device_count(void);
 /* Pin / unpin a caller-owned host buffer (hipHostRegister): host batches from pinned memory copy
@@ -215,6 +217,12 @@ int zc_ed_coset4(zc_ctx *ctx, const uint64_t *p, uint64_t *out4, size_t n);
  * generation; the 32-byte outputs are bit-identical to the reference's.                     */
 int zc_ed_mul_base(zc_ctx *ctx, const uint64_t *k, uint64_t *out, size_t n);
 int zc_ris_mul_base_compress(zc_ctx *ctx, const uint64_t *k, uint8_t *out32, size_t n);
+/* window_naf_mul itself, src/edwards.rs:155-171, in ONE launch, with its two defects repaired: digit d selects entry
+ * (|d| + 1) / 2 of BASEPOINT_ODD_MULTIPLES_TABLE (backend/u64/constants.rs:216-972: entry j = (2j - 1) B; the reference
+ * indexes with d itself), and all 256 digits of compute_window_NAF(width) (backend/u64/scalar.rs:396-415, reproduced
+ * literally) are read, not only 249..0.  out = (sum_i d_i 2^i) B: `&BASEPOINT * &k` under == for every canonical k.
+ * width 2..7 (the digits are i8), else ZC_ERR_BAD_ARG.  The table is rebuilt on the device (cached affine records).   */
+int zc_ed_mul_base_wnaf(zc_ctx *ctx, const uint64_t *k, unsigned width, uint64_t *out, size_t n);
 
 /* ---- multi-scalar multiplication (not in the reference: sum_i k_i * P_i) -------- */
 /* out_point: one EdwardsPoint (HOST memory), equal to the reference's
@@ -236,9 +244,16 @@ int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t 
  *                       ordered fold -> out_point (HOST memory), identical limbs on every rank.
  *                       (Point addition is not an ncclRedOp_t: all-gather + fold, not all-reduce.)
  *                       A rank whose local part fails still joins the collective (with a poison
- *                       record) and EVERY rank returns an error: nobody is left waiting.          */
+ *                       record) and EVERY rank returns an error: nobody is left waiting.
+ *   zc_msm_plan         a query, no device work: what the bucket method would do for a shard of n pairs on this
+ *                       context -- out8 = {window bits c (0: below the bucket threshold, n scalar multiplications +
+ *                       folds), windows W, 1 = affine 96-byte records and 7-multiplication additions / 0 = projective
+ *                       128-byte records and 8, bytes per gathered record, run length of the bucket-sum kernel,
+ *                       buckets per reduction segment, sort passes, 0}.  What a roofline record counts its useful
+ *                       work from (bench.py); points_aligned16: whether the point array is 16-byte aligned.           */
 int zc_msm_partial(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
                    uint64_t *out_dev_point);
+int zc_msm_plan(zc_ctx *ctx, size_t n, int points_aligned16, int32_t *out8);
 int zc_ed_fold_ordered(zc_ctx *ctx, const uint64_t *parts, size_t count, uint64_t *out);
 int zc_comm_unique_id(uint8_t *id_out128);
 int zc_comm_init(zc_ctx *ctx, const uint8_t *id128, int rank, int world);

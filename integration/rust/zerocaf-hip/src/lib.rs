@@ -562,6 +562,23 @@ impl HipBackend {
         Ok(unflat_ed(&self.un(ffi::zc_ed_mul_base, &flat_sc(k), k.len(), 20)?))
     }
 
+    /// `window_naf_mul` (src/edwards.rs:155-171) with its table indexed correctly, in one launch;
+    /// `width` 2..=7.  Equal to `&BASEPOINT * &k` under `==` for canonical scalars.
+    pub fn ed_mul_base_wnaf(&self, k: &[Scalar], width: u8) -> Result<Vec<EdwardsPoint>> {
+        let fk = flat_sc(k);
+        let mut out = vec![0u64; 20 * k.len()];
+        check(unsafe { ffi::zc_ed_mul_base_wnaf(self.ctx, fk.as_ptr(), width as u32, out.as_mut_ptr(), k.len()) })?;
+        Ok(unflat_ed(&out))
+    }
+
+    /// The bucket method's plan for a shard of `n` pairs on this context (a query, no device work):
+    /// `[c, W, affine, record bytes, run length, buckets per segment, sort passes, 0]`.
+    pub fn msm_plan(&self, n: usize, points_aligned16: bool) -> Result<[i32; 8]> {
+        let mut v = [0i32; 8];
+        check(unsafe { ffi::zc_msm_plan(self.ctx, n, points_aligned16 as i32, v.as_mut_ptr()) })?;
+        Ok(v)
+    }
+
     /// `sum_i k_i * P_i` (bucket method); equal to the fold of `Mul` and `Add` under `==`.
     pub fn msm(&self, p: &[EdwardsPoint], k: &[Scalar]) -> Result<EdwardsPoint> {
         assert_eq!(p.len(), k.len());

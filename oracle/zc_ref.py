@@ -16,10 +16,55 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libzc_ref.so")
 
 
+CFLAGS = "-O3 -march=native -fPIC -std=c11 -Wall -Wextra"       # SURVEY 8(d) / BASELINE.md: the CPU baseline is built -march=native
+
+
+def _host_stamp() -> str:
+    """Identifies the host the library was built FOR: -march=native code must not travel to another CPU model (the
+    in-tree .so is copied to the GPU box with the snapshot), so build() rebuilds when the stamp differs."""
+    import hashlib
+    model, flags = "", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = line.split(":", 1)[1].strip()
+            if model and flags:
+                break
+    except OSError:
+        pass
+    return "%s|%s|%s" % (model, hashlib.sha256(flags.encode()).hexdigest()[:16], CFLAGS)
+
+
+def build_flags() -> str:
+    return CFLAGS
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "zc_ref.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "libzc_ref.so"], stdout=subprocess.DEVNULL)
+    """Compile oracle/libzc_ref.so on THIS host (gcc -O3 -march=native) unless an up-to-date build for this very CPU
+    is already there.  Safe against concurrent callers (ranks of one job): lock file + atomic rename."""
+    import fcntl
+    src, stamp_path = os.path.join(_HERE, "zc_ref.c"), _SO + ".host"
+    want = _host_stamp()
+
+    def fresh() -> bool:
+        try:
+            return (os.path.getmtime(_SO) >= os.path.getmtime(src) and os.path.getmtime(_SO) >= os.path.getmtime(os.path.join(_HERE, "zc_ref.h"))
+                    and open(stamp_path).read() == want)
+        except OSError:
+            return False
+    if not force and fresh():
+        return _SO
+    with open(_SO + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = "%s.%d.tmp" % (_SO, os.getpid())
+            subprocess.check_call(["make", "-B", "-C", _HERE, "libzc_ref.so", "OUT=" + tmp, "CFLAGS=" + CFLAGS], stdout=subprocess.DEVNULL)
+            os.replace(tmp, _SO)
+            with open(stamp_path + ".tmp", "w") as f:
+                f.write(want)
+            os.replace(stamp_path + ".tmp", stamp_path)
     return _SO
 
 
@@ -29,8 +74,7 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()                                                  # rebuilds when the .so was made for another CPU model
         _lib = C.CDLL(_SO)
     return _lib
 

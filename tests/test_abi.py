@@ -58,6 +58,29 @@ def test_no_cpu_fallback_and_no_oracle_linkage(lib):
                 assert "zc_ref" not in src and "from oracle" not in src and "import oracle" not in src, f
 
 
+def test_release_library_carries_no_test_hooks_and_reads_its_knobs_once(lib):
+    """Fault injection (ZC_TEST_RING_POISON / ZC_TEST_RING_SPINS) and the stage hooks (zc_test_*) exist only in
+    libzerocaf_hip_test.so, the -DZC_TEST_HOOKS build the GPU test tier loads beside the product; the release library
+    has neither the symbols nor the strings.  Tuning knobs are read in ONE place (tuning_from_env, at zc_ctx_create)."""
+    import dusk_zerocaf_amd as z
+    from dusk_zerocaf_amd import _lib
+    rel = subprocess.check_output(["nm", "-D", "--defined-only", z.LIB_PATH], text=True)
+    assert "zc_test_" not in rel
+    assert b"ZC_TEST_" not in open(z.LIB_PATH, "rb").read()
+    tst = subprocess.check_output(["nm", "-D", "--defined-only", _lib.TEST_LIB_PATH], text=True)
+    assert {"zc_test_msm_sort", "zc_test_odd_table"} <= set(re.findall(r"\bT (zc_[a-z0-9_]+)", tst))
+    assert set(re.findall(r"\bT (zc_[a-z0-9_]+)", rel)) == set(re.findall(r"\bT (zc_[a-z0-9_]+)", tst)) - {"zc_test_msm_sort", "zc_test_odd_table"}
+    src = ""
+    for f in os.listdir(os.path.join(ROOT, "dusk_zerocaf_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            src += open(os.path.join(ROOT, "dusk_zerocaf_amd", "csrc", f)).read()
+    body = src[src.index("Tuning tuning_from_env()"):]
+    body = body[:body.index("\n}\n")]
+    outside = src.replace(body, "")
+    assert re.findall(r"getenv\(\"(ZC_[A-Z_0-9]+)\"\)", outside) == ["ZC_RCCL_PATH"]     # where librccl lives: not a tuning knob
+    assert "env_long(" in body and outside.count("env_long(") == 1                      # its definition only
+
+
 def test_rust_shim_binds_the_whole_abi():
     """integration/rust/zerocaf-hip (source only: no Rust toolchain here) declares every entry
     point of the header -- ffi.rs is generated from it -- and its safe layer calls each one."""

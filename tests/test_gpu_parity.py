@@ -239,7 +239,7 @@ def test_fe_invert_bulk(eng, oracle):
     assert (prod[nz, 0] == 1).all() and not prod[nz, 1:].any() and not inv[~nz].any()
 
 
-def test_batched_inversion_chunk_lengths(eng, oracle, monkeypatch):
+def test_batched_inversion_chunk_lengths(oracle):
     """Montgomery's trick over strided chunks (lane g takes g, g + lanes, ...) around the division-step
     inversion: every chunk length, ragged batch sizes that leave the last chunks short, zeros inside --
     invert, Div and to_affine must not depend on the chunking and must equal the oracle."""
@@ -254,17 +254,16 @@ def test_batched_inversion_chunk_lengths(eng, oracle, monkeypatch):
         wq, wqok = oracle.fe_div(num[:m], a[:m])
         wxy, waok = oracle.mt(oracle.ed_to_affine, P)
         for c in ("1", "2", "3", "5", "16", "32", "64"):
-            monkeypatch.setenv("ZC_INV_CHUNK", c)
-            inv, ok = eng.fe_invert(a)
-            q, qok = eng.fe_div(num, a)
-            xy, aok = eng.ed_to_affine(P)
+            with V.tuned(ZC_INV_CHUNK=c) as te:
+                inv, ok = te.fe_invert(a)
+                q, qok = te.fe_div(num, a)
+                xy, aok = te.ed_to_affine(P)
             assert eq(inv[:m], winv) and eq(ok[:m], wok) and eq(q[:m], wq) and eq(qok[:m], wqok), (n, c)
             assert eq(xy, wxy) and eq(aok, waok), (n, c)
             if c == "1":
                 ref = (inv, ok, q, qok)
             else:
                 assert all(eq(x, y) for x, y in zip(ref, (inv, ok, q, qok))), (n, c)
-    monkeypatch.delenv("ZC_INV_CHUNK")
 
 
 def test_fe_invert_chunked_exact(eng, oracle):
@@ -308,7 +307,7 @@ def test_sqrt_ratio_bulk(eng, oracle):
     assert eq(sq, wsq) and eq(out, want) and 0 < sq.sum() < n
 
 
-def test_field_f8_rows(eng, oracle, kats, monkeypatch):
+def test_field_f8_rows(eng, oracle, kats):
     """F7/F8/F9 leftovers: Div, Half, Pow, legendre_symbol, ModSqrt (both signs), is_positive --
     reference KATs (division, a_pow_b, legendre_symbol, mod_sqrt_tonelli_shanks) and bulk parity."""
     f = lambda n: np.array([kats["field"][n]["limbs"]], dtype=np.uint64)
@@ -338,13 +337,9 @@ def test_field_f8_rows(eng, oracle, kats, monkeypatch):
     big = V.rand_fe_np(1 << 16, V.SEED + 323)
     big[::97] = 0
     wl = oracle.mt(oracle.fe_legendre_symbol, big)
-    for rounds in (None, 26, 2):
-        if rounds is None:
-            monkeypatch.delenv("ZC_JACOBI_ROUNDS", raising=False)
-        else:
-            monkeypatch.setenv("ZC_JACOBI_ROUNDS", str(rounds))
-        assert eq(eng.fe_legendre_symbol(big), wl), rounds
-    monkeypatch.delenv("ZC_JACOBI_ROUNDS", raising=False)
+    for rounds in (None, 26, 2, 0):
+        with V.tuned(ZC_JACOBI_ROUNDS=rounds) as te:
+            assert eq(te.fe_legendre_symbol(big), wl), rounds
     assert eq(eng.fe_is_positive(x), oracle.fe_is_positive(x))
     raw = np.random.default_rng(V.SEED + 142).integers(0, 1 << 52, size=(n, 5), dtype=np.uint64)       # non-canonical limbs too
     assert eq(eng.fe_is_positive(raw), oracle.fe_is_positive(raw))
@@ -720,7 +715,7 @@ def test_ristretto_roundtrip_full_size_2_22(eng, oracle):
         assert eq(ok1[part], wok) and eq(r1[part], wout) and (wok == 0).sum() > 1000, lo
 
 
-def test_windowed_core_table_ring_under_contention(eng, oracle, monkeypatch):
+def test_windowed_core_table_ring_under_contention(eng, oracle):
     """The windowed core keeps its per-lane tables in a ring of wave slots per XCD (ring_acquire /
     ring_release, zc_kernels.hip.h).  With the default 512 slots per XCD a wave practically never waits
     for a slot; ZC_RING_SLOTS shrinks the ring far below the number of resident waves, so that every
@@ -742,41 +737,86 @@ def test_windowed_core_table_ring_under_contention(eng, oracle, monkeypatch):
     wout, wok = oracle.mt(oracle.ris_roundtrip_mul, enc[idx], K[idx])
     assert eq(ref_out[idx], wout) and eq(ref_ok[idx], wok)
     for slots in ("96", "7", "1"):                                 # 384 waves are resident per XCD
-        monkeypatch.setenv("ZC_RING_SLOTS", slots)
         m = n if slots != "1" else 1 << 13                          # one slot per XCD serialises the XCD's waves
-        out, ok = eng.ris_roundtrip_mul(enc[:m], K[:m])
-        assert eq(out, ref_out[:m]) and eq(ok, ref_ok[:m]), "ring of %s slots per XCD" % slots
-        pts = eng.ed_scalar_mul(P[:m], K[:m], flags=z.FAST)
-        assert eq(pts, ref_pts[:m]), "ring of %s slots per XCD (points)" % slots
-    monkeypatch.delenv("ZC_RING_SLOTS")
+        with V.tuned(ZC_RING_SLOTS=slots) as te:
+            out, ok = te.ris_roundtrip_mul(enc[:m], K[:m])
+            assert eq(out, ref_out[:m]) and eq(ok, ref_ok[:m]), "ring of %s slots per XCD" % slots
+            pts = te.ed_scalar_mul(P[:m], K[:m], flags=z.FAST)
+            assert eq(pts, ref_pts[:m]), "ring of %s slots per XCD (points)" % slots
+            out, ok = te.ris_roundtrip_mul(enc[:m], K[:m])          # and the state is reset per launch
+            assert eq(out, ref_out[:m]) and eq(ok, ref_ok[:m])
     out, ok = eng.ris_roundtrip_mul(enc, K)                        # and the state is reset per launch
     assert eq(out, ref_out) and eq(ok, ref_ok)
 
 
-def test_windowed_core_ring_timeout_is_reported_and_the_context_survives(eng, monkeypatch):
-    """A wave that gives up waiting for its table slot sets the ring's error word instead of trapping (a trap is a
-    sticky HIP error that kills every later call of the process).  The host reads the word at the next
-    synchronisation of the device, reports ZC_ERR_HIP once, clears it, and the context keeps working.  The hook
-    ZC_TEST_RING_POISON sets the word the way a timed-out wave would."""
+def test_windowed_core_ring_timeout_is_reported_and_the_context_survives(eng):
+    """A wave that gives up waiting for its table slot sets the device's error word (pinned host memory) instead of
+    trapping (a trap is a sticky HIP error that kills every later call of the process).  The host looks at the word at
+    every entry point and synchronisation that touches the device, reports ZC_ERR_HIP once, clears it, and the context
+    keeps working.  The hook ZC_TEST_RING_POISON (libzerocaf_hip_test.so only) sets the word the way a timed-out wave would."""
     import dusk_zerocaf_amd as z
+    import torch
     n = 4096
     K = V.rand_scalars_np(n, V.SEED + 143, bits=252)
     P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 144, bits=249))
     good = eng.ed_scalar_mul(P, K, flags=z.FAST)
-    monkeypatch.setenv("ZC_TEST_RING_POISON", "1")
-    with pytest.raises(Exception, match="table slot"):
-        eng.ed_scalar_mul(P, K, flags=z.FAST)                      # host batch: synchronises, sees the word
-    monkeypatch.delenv("ZC_TEST_RING_POISON")
-    assert eq(eng.ed_scalar_mul(P, K, flags=z.FAST), good)         # reported once, cleared, context intact
+    with V.tuned(hooks=True, ZC_TEST_RING_POISON=1) as te:
+        with pytest.raises(Exception, match="table slot"):
+            te.ed_scalar_mul(P, K, flags=z.FAST)                   # host batch: synchronises, sees the word
+        assert eq(te.fe_mul(K, K), eng.fe_mul(K, K))               # reported once, cleared, context intact
+        dP, dK = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, K))
+        te.ed_scalar_mul(dP, dK, flags=z.FAST)                     # device batch: asynchronous, no report yet
+        torch.cuda.synchronize()                                   # the caller synchronises its own stream ...
+        with pytest.raises(Exception, match="table slot"):
+            te.fe_mul(dK, dK)                                      # ... and the NEXT entry point on that device reports it
+        te.fe_mul(dK, dK)
+        te.ed_scalar_mul(dP, dK, flags=z.FAST)
+        with pytest.raises(Exception, match="table slot"):
+            te.synchronize()                                       # and so does zc_ctx_synchronize
+        te.synchronize()
+    with pytest.raises(AttributeError):
+        eng.lib.zc_test_msm_sort                                   # the release library carries no test hook
+    assert eq(eng.ed_scalar_mul(P, K, flags=z.FAST), good)
+
+
+def test_windowed_core_waves_that_give_up_write_poison_and_fail_closed(eng, oracle):
+    """The real give-up path (not the injected word): one table slot per XCD and a spin limit of 2^4 polls
+    (ZC_TEST_RING_SPINS, test build only), so most waves of the launch give up.  A wave that gives up must not touch
+    a slot it does not own: its rows are poison (all ones, ok = 0), every other row is the oracle's, the call reports
+    the failure, and the release library on the same device is unaffected."""
+    import dusk_zerocaf_amd as z
+    n = 1 << 14
+    K = V.rand_scalars_np(n, V.SEED + 145, bits=252)
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 146, bits=249))
+    enc = eng.ris_compress(P)
+    want_pts = eng.ed_scalar_mul(P, K, flags=z.FAST)
+    want_enc, want_ok = eng.ris_roundtrip_mul(enc, K)
+    idx = np.arange(0, n, 41)
+    wout, wok = oracle.mt(oracle.ris_roundtrip_mul, enc[idx], K[idx])
+    assert eq(want_enc[idx], wout) and eq(want_ok[idx], wok)
     import torch
-    dP, dK = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, K))
-    monkeypatch.setenv("ZC_TEST_RING_POISON", "1")
-    eng.ed_scalar_mul(dP, dK, flags=z.FAST)                        # device batch: asynchronous, no report yet
-    monkeypatch.delenv("ZC_TEST_RING_POISON")
-    with pytest.raises(Exception, match="table slot"):
-        eng.synchronize()
-    eng.synchronize()
-    assert eq(eng.ed_scalar_mul(dP, dK, flags=z.FAST).cpu().numpy().view(np.uint64), good)
+    with V.tuned(hooks=True, ZC_RING_SLOTS=1, ZC_TEST_RING_SPINS=4) as te:
+        dP, dK, dE = (torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda() for a in (P, K, enc))
+        pts = te.ed_scalar_mul(dP, dK, flags=z.FAST)
+        torch.cuda.synchronize()
+        with pytest.raises(Exception, match="table slot"):
+            te.synchronize()
+        pts = pts.cpu().numpy().view(np.uint64)
+        poisoned = (pts == np.uint64(0xFFFFFFFFFFFFFFFF)).all(axis=1)
+        assert 0 < poisoned.sum() < n, poisoned.sum()
+        assert (poisoned.reshape(-1, 64).all(axis=1) == poisoned.reshape(-1, 64).any(axis=1)).all()    # whole waves
+        assert eq(pts[~poisoned], want_pts[~poisoned])
+        out, ok = te.ris_roundtrip_mul(dE, dK)
+        torch.cuda.synchronize()
+        with pytest.raises(Exception, match="table slot"):
+            te.synchronize()
+        out, ok = out.cpu().numpy(), ok.cpu().numpy()
+        poisoned = (out == 0xFF).all(axis=1)
+        assert 0 < poisoned.sum() < n and (ok[poisoned] == 0).all()
+        assert eq(out[~poisoned], want_enc[~poisoned]) and eq(ok[~poisoned], want_ok[~poisoned])
+        with pytest.raises(Exception, match="table slot"):
+            te.ris_roundtrip_mul(enc, K)                           # host batch: reported by the call itself
+    assert eq(eng.ris_roundtrip_mul(enc, K)[0], want_enc)
 
 
 def test_next_rows_elligator_validity_projective(eng, oracle, kats):
@@ -878,6 +918,60 @@ def test_reference_odd_multiples_table_and_window_naf_mul_on_the_gpu(eng, oracle
         assert eq(eng.ed_compress(acc)[0], eng.ed_compress(want)[0]), w
 
 
+def test_window_naf_mul_in_one_launch(eng, oracle, kats):
+    """zc_ed_mul_base_wnaf: the reference's window_naf_mul (edwards.rs:155-171) as ONE kernel over the odd multiples
+    of the basepoint, table indexed as (|d| + 1) / 2 and all 256 digits read.  (i) The table the device builds, entry
+    by entry, against BASEPOINT_ODD_MULTIPLES_TABLE (constants.rs:216-972) through the test build's dump hook; (ii)
+    every width 2..7: the result equals the oracle's `&BASEPOINT * &k` (double_and_add) for canonical scalars, the
+    comb's result, and -- for raw patterns above L, where compute_window_NAF's modular subtraction wraps -- the point
+    (sum_i d_i 2^i) B of the ORACLE's digits; (iii) bad widths are refused."""
+    import torch
+    table = np.array([sum(p, []) for p in kats["odd_multiples_table"]["points"]], dtype=np.uint64)
+    with V.tuned(hooks=True) as te:
+        dump = torch.empty((125, 20), dtype=torch.int64, device="cuda")
+        assert te.lib.zc_test_odd_table(te.ctx, dump.data_ptr()) == 0, te.lib.zc_last_error()
+        dump = dump.cpu().numpy().view(np.uint64)
+    assert eng.ed_eq(dump, table[1:]).tolist() == [1] * 125 and eng.ed_is_valid(dump).tolist() == [1] * 125
+    n = 3000
+    K = V.rand_scalars_np(n, V.SEED + 330, bits=249)
+    K[0] = 0
+    K[1] = [1, 0, 0, 0, 0]
+    K[2] = V.limbs_array([pm.L - 1])[0]
+    K[3] = V.limbs_array([pm.L - 2])[0]
+    K[4] = V.limbs_array([(1 << 249) - 1])[0]
+    K[5:5 + 125, :] = 0
+    K[5:5 + 125, 0] = np.arange(1, 250, 2)                          # the odd multiples themselves
+    K[130:130 + 64] = V.limbs_array([pm.L - 1 - j for j in range(64)])         # near L: the recoder's wrap-around zone
+    base = np.tile(table[1:2], (n, 1))
+    want = oracle.mt(oracle.ed_scalar_mul, base, K)
+    comb = eng.ed_mul_base(K)
+    assert oracle.ed_eq(comb, want).all()
+    raw = np.concatenate([V.raw_scalar_edges(n_random=60), V.rand_scalars_np(200, V.SEED + 331, bits=252)])   # mostly >= L
+    for w in range(2, 8):
+        got = eng.ed_mul_base_wnaf(K, w)
+        naf = np.asarray(oracle.sc_compute_naf(K, w)).astype(np.int64)
+        vals = [sum(int(d) << i for i, d in enumerate(row)) % pm.L for row in naf]
+        kv = [sum(int(K[i, j]) << (52 * j) for j in range(5)) for i in range(n)]
+        exact = np.array([a == b for a, b in zip(vals, kv)])
+        assert exact[:5 + 125].all()                               # the digits of small / ordinary scalars represent them
+        assert oracle.ed_eq(got[exact], want[exact]).all(), w
+        assert eq(eng.ed_compress(got[exact])[0], eng.ed_compress(comb[exact])[0]), w
+        if (~exact).any():                                         # near L the reference's digits stand for another integer: follow them
+            wv = oracle.mt(oracle.ed_scalar_mul, base[~exact], V.limbs_array([v for v, e in zip(vals, exact) if not e]))
+            assert oracle.ed_eq(got[~exact], wv).all(), w
+        gr = eng.ed_mul_base_wnaf(raw, w)
+        nr = np.asarray(oracle.sc_compute_naf(raw, w)).astype(np.int64)
+        vr = V.limbs_array([sum(int(d) << i for i, d in enumerate(row)) % pm.L for row in nr])
+        assert oracle.ed_eq(gr, oracle.mt(oracle.ed_scalar_mul, base[:len(raw)], vr)).all(), w
+    big = (1 << 17) + 5                                            # a full-chip launch, device pointers
+    Kb = V.rand_scalars_np(big, V.SEED + 332, bits=249)
+    dK = torch.from_numpy(Kb.view(np.int64)).cuda()
+    assert eq(eng.ris_compress(eng.ed_mul_base_wnaf(dK, 5)).cpu().numpy(), eng.ris_mul_base_compress(Kb))
+    for bad in (0, 1, 8, 200):
+        with pytest.raises(Exception, match="width"):
+            eng.ed_mul_base_wnaf(K[:4], bad)
+
+
 def test_fixed_base_comb_digit_edges(eng, oracle):
     """The radix-256 comb recodes a scalar into signed digits in [-128, 128) with a carry that can run
     through every window: byte patterns 0x80 / 0x7f / 0xff / 0x00 in every position and mix, raw limb
@@ -957,21 +1051,11 @@ def _msm_sort_model(K, c):
 @pytest.mark.parametrize("n,c,g,packed", [(1000, 5, None, 1), (3 * 4096 + 17, 9, None, 1), (3 * 4096 + 17, 10, 2, 1), (3 * 4096 + 17, 10, 2, 0),
                                           (70001, 13, None, 1), (70001, 17, 3, 1), (70001, 17, 3, 0), (40000, 19, None, 1),
                                           (40000, 19, 2, 0), (40000, 19, 2, 2), (3 * 8192 + 5, 9, 2, 2), (20000, 20, None, 1), (9000, 22, 1, 1)])
-def test_msm_key_sort_is_the_stable_bucket_order(eng, n, c, g, packed, monkeypatch):
+def test_msm_key_sort_is_the_stable_bucket_order(n, c, g, packed):
     """The hand-written per-window LSD counting sort (zc_sort.hip.h) through its test hook: one, two and three
     passes, the one-word and the two-word intermediate of the two-pass sort, partial tiles, several tiles per
     column, skewed digits -- pair for pair the stable sort's output."""
-    import ctypes as C
     import torch
-    if g is None:
-        monkeypatch.delenv("ZC_MSM_SORT_G", raising=False)
-    else:
-        monkeypatch.setenv("ZC_MSM_SORT_G", str(g))
-    monkeypatch.setenv("ZC_MSM_SORT_PACKED", "1" if packed == 1 else "0")      # 0: two-word intermediate, 2: with tiles of 8192 keys
-    monkeypatch.setenv("ZC_MSM_SORT_BIG", "1" if packed == 2 else "0")
-    fn = eng.lib.zc_test_msm_sort
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    fn.restype = C.c_int
     K = V.rand_scalars_np(n, V.SEED + 300 + c, bits=252)
     K[0] = 0
     K[1] = [(1 << 52) - 1] * 5                                    # all 260 bits: the recoding carry reaches the top window
@@ -981,7 +1065,9 @@ def test_msm_key_sort_is_the_stable_bucket_order(eng, n, c, g, packed, monkeypat
     dK = torch.from_numpy(K.view(np.int64)).cuda()
     out = torch.empty((n * W, 2), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    assert fn(eng.ctx, dK.data_ptr(), n, c, out.data_ptr()) == 0, eng.lib.zc_last_error()
+    # 0: two-word intermediate, 2: with tiles of 8192 keys; the hook lives in the -DZC_TEST_HOOKS build only
+    with V.tuned(hooks=True, ZC_MSM_SORT_G=g, ZC_MSM_SORT_PACKED="1" if packed == 1 else "0", ZC_MSM_SORT_BIG="1" if packed == 2 else "0") as te:
+        assert te.lib.zc_test_msm_sort(te.ctx, dK.data_ptr(), n, c, out.data_ptr()) == 0, te.lib.zc_last_error()
     got = out.cpu().numpy().view(np.uint32)
     wk, wv = _msm_sort_model(K, c)
     assert eq(got[:, 0], wk)
@@ -1016,7 +1102,7 @@ def test_msm_bucket_method(eng, oracle, n, bits):
     assert eq(oracle.ris_compress(got), oracle.ris_compress(want))
 
 
-def test_msm_window_widths_vs_oracle(eng, oracle, monkeypatch):
+def test_msm_window_widths_vs_oracle(eng, oracle):
     """Window widths c = 5..19 (forced with ZC_MSM_WINDOW; the natural choice at 2^16 pairs is 13)
     against the ORACLE's sum of the reference's Mul<Scalar> + Add (edwards.rs:547-561, :465-489)."""
     n = (1 << 16) + 11
@@ -1027,12 +1113,12 @@ def test_msm_window_widths_vs_oracle(eng, oracle, monkeypatch):
     want = oracle.msm_naive_mt(P, K)
     wenc = oracle.ed_compress(want)[0]
     for c in (5, 10, 12, 13, 14, 15, 16, 17, 19):
-        monkeypatch.setenv("ZC_MSM_WINDOW", str(c))
-        got = eng.msm(P, K)
+        with V.tuned(ZC_MSM_WINDOW=c) as te:
+            got = te.msm(P, K)
         assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), c
 
 
-def test_msm_skewed_digit_distributions(eng, oracle, monkeypatch):
+def test_msm_skewed_digit_distributions(eng, oracle):
     """The bucket sums are a segmented reduction of the sorted (bucket, point) list in fixed-length
     runs, so skew costs nothing and must change nothing: every scalar equal (one bucket per window
     holds all n points), scalars of a few bits (most windows empty), a two-valued mix, and run lengths
@@ -1056,16 +1142,89 @@ def test_msm_skewed_digit_distributions(eng, oracle, monkeypatch):
         want = oracle.msm_naive_mt(P, K)
         wenc = oracle.ed_compress(want)[0]
         for run, c in ((None, None), (4, 8), (5, 11), (7, None), (64, 6), (4096, None)):
-            if run is None:
-                monkeypatch.delenv("ZC_MSM_RUN", raising=False)
-            else:
-                monkeypatch.setenv("ZC_MSM_RUN", str(run))
-            if c is None:
-                monkeypatch.delenv("ZC_MSM_WINDOW", raising=False)
-            else:
-                monkeypatch.setenv("ZC_MSM_WINDOW", str(c))
-            got = eng.msm(P, K)
+            with V.tuned(ZC_MSM_RUN=run, ZC_MSM_WINDOW=c) as te:
+                got = te.msm(P, K)
             assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), (name, run, c)
+
+
+@pytest.mark.parametrize("knobs", [
+    dict(ZC_MSM_AFFINE=0), dict(ZC_MSM_AFFINE=0, ZC_MSM_FORK=1), dict(ZC_MSM_FORK=0), dict(ZC_MSM_FORK=1),
+    dict(ZC_MSM_RUN_EDGES=4), dict(ZC_MSM_RUN_EDGES=32, ZC_MSM_RUN=16), dict(ZC_MSM_AFFINE_CHUNK=1), dict(ZC_MSM_AFFINE_CHUNK=5, ZC_MSM_SEG=4),
+    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
+    """Every MSM path a ZC_* knob can select in the shipped library (projective 128-byte records at a size where the
+    default is affine, the normalisation forked onto the second stream or kept in line, other edge-run lengths, other
+    normalisation chunkings and segment lengths), at 2^17 + 333 pairs (where the affine path and the persistent
+    structures are live), against the ORACLE's sum of the reference's Mul<Scalar> + Add."""
+    n = (1 << 17) + 333
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 410, bits=249))
+    K = V.rand_scalars_np(n, V.SEED + 411, bits=252)
+    K[:24] = V.raw_scalar_edges(n_random=0)
+    P[30] = V.IDENT_ROW
+    want = oracle.msm_naive_mt(P, K)
+    wenc = oracle.ed_compress(want)[0]
+    with V.tuned(**knobs) as te:
+        got = te.msm(P, K)
+        assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), knobs
+        small = te.msm(P[:5000], K[:5000])                         # and a shard below the affine threshold under the same knobs
+    wsmall = oracle.msm_naive_mt(P[:5000], K[:5000])
+    assert oracle.ed_eq(small, wsmall)[0] == 1, knobs
+    with V.tuned(ZC_MSM_AFFINE=1, **{k: v for k, v in knobs.items() if k != "ZC_MSM_AFFINE"}) as te:
+        assert oracle.ed_eq(te.msm(P[:5000], K[:5000]), wsmall)[0] == 1, knobs      # affine records forced on a small shard
+
+
+@pytest.mark.parametrize("knobs", [dict(ZC_SCHED="block"), dict(ZC_SCHED="block", ZC_BALANCE="global"), dict(ZC_BALANCE="global")],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_strict_scalar_mul_every_selectable_schedule_vs_oracle(eng, oracle, knobs):
+    """The strict kernels behind ZC_SCHED / ZC_BALANCE -- one workgroup per 256 elements with the block-local ranking
+    (`k_ed_scalar_mul` at >= 2^17 elements), the same kernels on the batch-wide cost-sorted permutation (the `idx`
+    branch of ed_scalar_mul_body) -- every (X:Y:Z:T) limb against the oracle's double_and_add (edwards.rs:102-120),
+    raw scalars >= 2^256 included, at 2^17 + 333 and at a size below the persistent-wave threshold."""
+    n = (1 << 17) + 333
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 420, bits=249))
+    K = V.rand_scalars_np(n, V.SEED + 421, bits=252)
+    _edge_scalars(K)
+    raw = V.raw_scalar_edges(n_random=40)
+    K[100:100 + len(raw)] = raw
+    K[n - len(raw):] = raw
+    want = oracle.mt(oracle.ed_scalar_mul, P, K)
+    assert eq(eng.ed_scalar_mul(P, K), want)
+    with V.tuned(**knobs) as te:
+        assert eq(te.ed_scalar_mul(P, K), want), knobs
+        m = (1 << 14) + 77                                         # block-shaped launch (and the permutation from 2^14 elements on)
+        assert eq(te.ed_scalar_mul(P[n - m:], K[n - m:]), want[n - m:]), knobs
+        import torch
+        dP, dK = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, K))
+        assert eq(te.ed_scalar_mul(dP, dK).cpu().numpy().view(np.uint64), want), knobs
+
+
+@pytest.mark.parametrize("knobs", [dict(ZC_RISTRETTO_STRICT=1), dict(ZC_RISTRETTO_STRICT=1, ZC_BALANCE="global")],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_ristretto_roundtrip_strict_sequence_kernel_vs_oracle(eng, oracle, knobs):
+    """ZC_RISTRETTO_STRICT=1 runs the fused config-4 kernel on the reference's formula sequence (`k_ris_roundtrip_mul`,
+    ristretto.rs:96-154 -> edwards.rs:102-120 -> ristretto.rs:398-425) instead of the windowed core: every output byte
+    and accept flag of 2^17 + 333 round trips with about 1 % undecodable inputs against the oracle, and against the
+    default kernel's bytes."""
+    n = (1 << 17) + 333
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 430, bits=249))
+    enc = eng.ris_compress(P)
+    rng = np.random.default_rng(V.SEED + 431)
+    bad = rng.choice(n, size=n // 100, replace=False)
+    enc[bad, :8] ^= rng.integers(1, 256, size=(len(bad), 8), dtype=np.uint8)
+    enc[7, 31] |= 0x80
+    K = V.rand_scalars_np(n, V.SEED + 432, bits=252)
+    _edge_scalars(K)
+    raw = V.raw_scalar_edges(n_random=40)
+    K[200:200 + len(raw)] = raw
+    wout, wok = oracle.mt(oracle.ris_roundtrip_mul, enc, K)
+    assert 0 < (wok == 0).sum() < n // 50
+    dout, dok = eng.ris_roundtrip_mul(enc, K)
+    assert eq(dout, wout) and eq(dok, wok)
+    with V.tuned(**knobs) as te:
+        out, ok = te.ris_roundtrip_mul(enc, K)
+        assert eq(out, wout) and eq(ok, wok), knobs
+        out, ok = te.ris_roundtrip_mul(enc[:3000], K[:3000])
+        assert eq(out, wout[:3000]) and eq(ok, wok[:3000]), knobs
 
 
 def test_msm_config5_shard_2_21_vs_oracle(eng, oracle):
@@ -1222,7 +1381,7 @@ def test_device_resident_windowed_core_chunks(eng, oracle):
     assert eq(oracle.ed_compress(Q.cpu().numpy().view(np.uint64)[sel])[0], oracle.ed_compress(want)[0])
 
 
-def test_host_batches_move_in_chunks(eng, oracle, monkeypatch):
+def test_host_batches_move_in_chunks(eng, oracle):
     """Host (numpy) batches of the scalar-mul family pass through the device in chunks that
     overlap copies with kernels; any chunking must give the bytes of the one-piece run, with
     ragged last chunks, optional masks and two device slots."""
@@ -1233,31 +1392,24 @@ def test_host_batches_move_in_chunks(eng, oracle, monkeypatch):
     K = V.rand_scalars_np(n, V.SEED + 131, bits=252)
     enc = eng.ris_compress(P)
     enc[5::1001, 31] |= 0x80                                       # some undecodable encodings
-    monkeypatch.setenv("ZC_HOST_CHUNKS", "1")
-    q1 = eng.ed_scalar_mul(P, K)
-    r1, ok1 = eng.ris_roundtrip_mul(enc, K)
-    c1 = eng.ed_mul_by_cofactor(P)
-    f1 = eng.fe_mul(K, K)
+    with V.tuned(ZC_HOST_CHUNKS=1) as te:
+        q1 = te.ed_scalar_mul(P, K)
+        r1, ok1 = te.ris_roundtrip_mul(enc, K)
+        c1 = te.ed_mul_by_cofactor(P)
+        f1 = te.fe_mul(K, K)
     sub = np.r_[0:256, (1 << 17) - 128:(1 << 17) + 128, n - 300:n]   # across chunk seams and the tail
     assert eq(q1[sub], oracle.ed_scalar_mul(P[sub], K[sub]))
     for chunks in (None, "3", "7"):
-        if chunks is None:
-            monkeypatch.delenv("ZC_HOST_CHUNKS")
-        else:
-            monkeypatch.setenv("ZC_HOST_CHUNKS", chunks)
-        assert eq(eng.ed_scalar_mul(P, K), q1)
-        fast = eng.ed_scalar_mul(P, K, flags=z.FAST)             # same group element: compare encodings
-        assert eq(eng.ed_compress(fast[sub])[0], eng.ed_compress(q1[sub])[0])
-        r, ok = eng.ris_roundtrip_mul(enc, K)
-        assert eq(r, r1) and eq(ok, ok1) and not ok[5] and ok[6]
-        assert eq(eng.ed_mul_by_cofactor(P), c1)
-        assert eq(eng.fe_mul(K, K), f1)
-    monkeypatch.setenv("ZC_HOST_CHUNKS", "5")
-    two = z.Engine([0, 0])
-    try:
+        with V.tuned(ZC_HOST_CHUNKS=chunks) as te:
+            assert eq(te.ed_scalar_mul(P, K), q1)
+            fast = te.ed_scalar_mul(P, K, flags=z.FAST)          # same group element: compare encodings
+            assert eq(te.ed_compress(fast[sub])[0], te.ed_compress(q1[sub])[0])
+            r, ok = te.ris_roundtrip_mul(enc, K)
+            assert eq(r, r1) and eq(ok, ok1) and not ok[5] and ok[6]
+            assert eq(te.ed_mul_by_cofactor(P), c1)
+            assert eq(te.fe_mul(K, K), f1)
+    with V.tuned(devices=[0, 0], ZC_HOST_CHUNKS=5) as two:
         assert eq(two.ed_scalar_mul(P, K), q1)
-    finally:
-        two.close()
 
 
 def test_concurrent_callers_share_a_context(eng, oracle):

@@ -79,3 +79,34 @@ def raw_scalar_edges(n_random=24, seed=SEED + 0x256):
     rnd[: n_random // 3, 4] &= ~np.uint64((1 << 48) - 1)
     rnd[: n_random // 3, 0] = rng.integers(0, 16, size=n_random // 3, dtype=np.uint64)
     return np.concatenate([np.array(rows, dtype=np.uint64), rnd])
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def tuned(hooks=False, devices=None, **env):
+    """An Engine whose context was created under the given ZC_* knobs (the library reads them once, in
+    zc_ctx_create).  hooks=True: on libzerocaf_hip_test.so, the -DZC_TEST_HOOKS build.  None values unset."""
+    import os
+    import dusk_zerocaf_amd as z
+    from dusk_zerocaf_amd import _lib
+    old = {k: os.environ.get(k) for k in env}
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    e = None
+    try:
+        e = z.Engine(devices, lib=_lib.load_test_hooks() if hooks else None)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        yield e
+    finally:
+        e.close()

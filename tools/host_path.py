@@ -44,19 +44,22 @@ def main():
     ref = tQ.cpu().numpy().view(np.uint64)
     out = np.empty_like(P)
 
-    def warm():
-        eng._call("zc_ed_scalar_mul", P.ctypes.data, k.ctypes.data, out.ctypes.data, n, 0)
-
-    def fresh():
-        o = np.empty_like(P)
-        eng._call("zc_ed_scalar_mul", P.ctypes.data, k.ctypes.data, o.ctypes.data, n, 0)
-
     for chunks in ("auto", "1", "2", "3", "4", "6", "8", "12", "16", "24", "32"):
         if chunks == "auto":
             os.environ.pop("ZC_HOST_CHUNKS", None)
         else:
             os.environ["ZC_HOST_CHUNKS"] = chunks
+        ce = z.Engine()                                            # knobs are read when a context is created
+
+        def warm():
+            ce._call("zc_ed_scalar_mul", P.ctypes.data, k.ctypes.data, out.ctypes.data, n, 0)
+
+        def fresh():
+            o = np.empty_like(P)
+            ce._call("zc_ed_scalar_mul", P.ctypes.data, k.ctypes.data, o.ctypes.data, n, 0)
+
         tw, tf = best(warm), best(fresh)
+        ce.close()
         assert np.array_equal(out, ref)
         print(json.dumps({"op": "ed_scalar_mul", "n": n, "chunks": chunks, "warm_ms": round(tw * 1e3, 2),
                           "fresh_ms": round(tf * 1e3, 2), "device_ms": round(t_dev * 1e3, 2),

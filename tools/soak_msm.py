@@ -42,6 +42,7 @@ for seed in range(first, first + count):
         knobs["ZC_MSM_AFFINE_CHUNK"] = int(rng.choice([1, 2, 5, 8, 16, 33]))
     for k, v in knobs.items():
         os.environ[k] = str(v)
+    meng = z.Engine()                                              # the library reads its knobs when a context is created
     bits = int(rng.choice([16, 64, 128, 249, 252]))
     K = V.rand_scalars_np(n, seed * 7 + 1, bits=252)
     if bits < 249:
@@ -71,7 +72,8 @@ for seed in range(first, first + count):
         assert bool(eng.ed_eq(P, Ph).all())
         P = Ph
     torch.cuda.synchronize()
-    got = eng.msm(P, torch.from_numpy(K.view(np.int64)).cuda())
+    got = meng.msm(P, torch.from_numpy(K.view(np.int64)).cuda())
+    meng.close()
     want = zc_ref.msm_naive_mt(P.cpu().numpy().view(np.uint64), K)
     ok = zc_ref.ed_eq(got, want)[0] == 1 and np.array_equal(zc_ref.ed_compress(got)[0], zc_ref.ed_compress(want)[0])
     print("soak_msm seed %d %s: n=%d bits=%d style=%.2f knobs=%s (%.1f s)" % (seed, "ok" if ok else "FAILED", n, bits, style, knobs, time.time() - t0), flush=True)
