@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: batched variable-base Edwards scalar multiplication
 (BASELINE.json configs[2]: 2^20 points x random 252-bit scalars per GPU) on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W          (defaults: K = 20, W = 5 -- the driver's own invocation; 0.5 s)
+    python bench.py --gpus 1 --steps K --warmup W          (defaults: K = 20, W = 5 -- the driver's own invocation)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of zc_ed_scalar_mul (strict mode: the reference's formula sequence,
@@ -10,20 +10,28 @@ bit-identical (X:Y:Z:T) limbs) over the rank's 2^20 HBM-resident points and scal
 Independent elements: the batch is sharded across ranks with no data-path collective
 (weak scaling: 2^20 per GPU).  `--workload msm` is the one path with an exchange step
 (BASELINE configs[4]): zc_msm_sharded = bucket method per GPU, ncclAllGather of the 160-byte
-partial sums inside the library, ordered fold on the device.
+partial sums inside the library, ordered fold on the device.  `--workload ecdh` is the reference's only
+macro-benchmark (benchmarks/dusk_benchmarks.rs:544-620): two key generations and two shared secrets per unit.
 PyTorch supplies device memory, the stream and torch.distributed; all arithmetic is in
 libzerocaf_hip.so.  The oracle (oracle/) is touched only after the timed region: the
 cpu_baseline leg (the same operation on the host cores) whose results double as the parity
 spot check of the GPU output (`--cpu-sample 0` skips both).
 Prints ONE JSON line on rank 0.
 
-roofline: the scalar-mul / Ristretto / MSM kernels are bound by the integer multiplier pipe
-(v_mad_u64_u32 class), not by HBM (0.2 % of 8 TB/s), so `bound` = "valu_int_mul":
+The default single-GPU run (the driver's) also carries `secondary`: the other BASELINE configs -- fe_mul 2^24 and
+fe_invert 2^20 (configs[1]), the Ristretto round trip 2^22 (configs[3]), the MSM shard 2^21 (configs[4]) -- and the ECDH
+exchange, a few steps each AFTER the headline's timed region and outside its ms_per_step, each with its own roofline
+record and oracle spot check (`--no-secondary` skips them).
+
+roofline (schema "useful-work/2", since round 3; rounds 1-2 reported issued work as `frac`): the scalar-mul / Ristretto /
+MSM / ECDH kernels are bound by the integer multiplier pipe (v_mad_u64_u32 class), not by HBM (0.2 % of 8 TB/s), so
+`bound` = "valu_int_mul":
   achieved = USEFUL v_mad_u64_u32 lane-operations per second: the multiplications the algorithm needs x 135 per
              Montgomery multiplication / kernel time (HIP events, live) -- no profile input at all.  Strict scalar-mul:
              sum over this run's scalars of (bitlen - 1 + popcount) evaluations of the reference's addition formula x 9
-             multiplications; MSM: non-zero window digits x 7 multiplications (the mixed addition of the bucket sums);
-             Ristretto round trip: the windowed core's fixed schedule + the two codecs.
+             multiplications; MSM: non-zero window digits x the multiplications of one bucket addition (7 with affine
+             records, 8 without -- the library's own plan, zc_msm_plan); Ristretto round trip: the windowed core's fixed
+             schedule + the two codecs; ECDH: two comb multiplications + two encodings + two round trips.
   peak     = one multiplier-class wave-instruction per 4 shader cycles per SIMD at the nominal clock (a hard
              roof: 39.3 T lane-ops/s); `measured_rate` = the saturated v_mad_u64_u32 rate of this board measured
              in this run (libzc_ubench.so), with the same fractions against it
@@ -39,7 +47,6 @@ is cache bandwidth, not HBM).  fe_invert is neither: `bound` = "latency/occupanc
 from __future__ import annotations
 
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -52,6 +59,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 MADS_PER_MUL = 135               # v_mad_u64_u32 per Montgomery multiplication (zc_arith.hip.h, column-ordered)
+MADS_PER_SQR = 99
+ROOFLINE_SCHEMA = "useful-work/2"
 WORKLOADS = {
     # algorithmic bytes per unit: SURVEY 8(d)
     "scalar_mul": {"bytes": 360, "kernel": "k_ed_scalar_mul_pw (+ k_sm_cost_hist/scan/scatter)", "bound": "valu_int_mul", "unit": "scalar-muls/s"},
@@ -60,21 +69,36 @@ WORKLOADS = {
     "ristretto": {"bytes": 104, "kernel": "k_ris_roundtrip_mul_fast", "bound": "valu_int_mul", "unit": "round-trips/s"},
     "msm": {"bytes": 200, "kernel": "k_msm_runs_affine (+ k_msm_digits, k_msm_sort_hist/scatter + k_scan_*, k_msm_prepare_affine, k_msm_runs_edges/segments/fold_groups/window_combine)",
             "bound": "valu_int_mul", "unit": "pairs/s"},
+    # two secret scalars in, two public keys and two shared secrets out (32-byte Ristretto encodings)
+    "ecdh": {"bytes": 80 + 128, "kernel": "2 x k_ris_mul_base_compress + 2 x k_ris_roundtrip_mul_fast", "bound": "valu_int_mul", "unit": "exchanges/s"},
 }
 INFINITY_CACHE_BYTES = 256 << 20
 HBM_COPY_GBS = 6290.0            # MI355X_MICROARCH.md: what a device-to-device copy reaches (the achievable HBM rate)
+WINDOW_MADS = 4 * (4 * MADS_PER_SQR + 3 * MADS_PER_MUL) + MADS_PER_MUL + 8 * MADS_PER_MUL     # one 4-bit window of the windowed core
+CODEC_MADS = 250 * MADS_PER_SQR + 61 * MADS_PER_MUL          # one (p-5)/8 power (~250 squarings + ~36 multiplications) + ~25 multiplications of glue
+ROUNDTRIP_MADS = 63 * WINDOW_MADS + 55 * MADS_PER_MUL + 2 * CODEC_MADS
+KEYGEN_MADS = 33 * 7 * MADS_PER_MUL + CODEC_MADS             # radix-256 comb: 33 mixed additions, then one encoding
+# BASEPOINT (src/backend/u64/constants.rs:188-211), X | Y | Z | T limbs: the operand of the reference's key generation
+BASEPOINT_LIMBS = [276718085098056, 1646536057461434, 2704687245600312, 2630386667454967, 13476148227069,
+                   1303868825475266, 3250718520537114, 2702159777242978, 2702159776422297, 10555311626649,
+                   1, 0, 0, 0, 0,
+                   3634527586288175, 2006028620404053, 3424252198034825, 2478951925947079, 4567251727358]
 
 
-def msm_window_bits(n):
-    """The window width zc_msm picks for a shard of n pairs (zerocaf_hip.hip: msm_window_bits)."""
-    c = max(5, n.bit_length() - 1 - 4)
-    if c in (15, 16):
-        c = 17
-    c = min(c, 18)
-    e = os.environ.get("ZC_MSM_WINDOW")
-    if e and 5 <= int(e) <= 22:
-        c = int(e)
-    return c
+def size_label(n):
+    """2^k for powers of two, the number otherwise -- so that a record names the size it was taken at."""
+    return "2^%d" % (n.bit_length() - 1) if n > 0 and n & (n - 1) == 0 else str(n)
+
+
+def workload_label(wl, n, bits, ecdh="wire"):
+    s = size_label(n)
+    return {"scalar_mul": "%s EdwardsPoint variable-base scalar-mul, random %d-bit scalars (BASELINE configs[2])" % (s, bits),
+            "fe_mul": "%s FieldElement mul (BASELINE configs[1])" % s,
+            "fe_invert": "%s FieldElement invert (BASELINE configs[1]); division-step inversion shared by up to 32 elements per lane" % s,
+            "ristretto": "%s Ristretto decompress->scalar-mul->compress, random %d-bit scalars, ~1%% undecodable inputs (BASELINE configs[3] shape)" % (s, bits),
+            "msm": "%s-pair Pippenger MSM, %d-bit scalars, one shard per GPU (BASELINE configs[4] shape)" % (s, bits),
+            "ecdh": "%s ECDH exchanges (benchmarks/dusk_benchmarks.rs:544-620): two key generations + two shared secrets per unit, %d-bit secrets, %s"
+                    % (s, bits, "32-byte Ristretto encodings on the wire" if ecdh == "wire" else "the reference's double_and_add on extended points")}[wl]
 
 
 def msm_nonzero_digits(K, c):
@@ -99,14 +123,45 @@ def msm_nonzero_digits(K, c):
     return total, W
 
 
+def strict_formula_evaluations(K):
+    """sum over the scalars of (bitlen - 1 + popcount): evaluations of the reference's addition formula in double_and_add."""
+    n = len(K)
+    bits = np.zeros(n, dtype=np.int64)
+    pop = np.zeros(n, dtype=np.int64)
+    for j in range(5):
+        x = K[:, j]
+        nz = x != 0
+        bl = np.zeros(n, dtype=np.int64)
+        bl[nz] = np.floor(np.log2(x[nz].astype(np.float64))).astype(np.int64) + 1
+        bits = np.where(nz, 52 * j + bl, bits)
+        pop += _popcount64(x)
+    return int(np.sum(np.where(bits > 0, bits - 1 + pop, 0)))
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_inputs(eng, torch, n, seed, workload, scalar_bits=252):
+class Env:
+    """What every workload of one bench.py process shares."""
+    def __init__(self, torch, z, eng, stream, rank, world, backend, dist):
+        self.torch, self.z, self.eng, self.stream = torch, z, eng, stream
+        self.rank, self.world, self.backend, self.dist = rank, world, backend, dist
+        self.measured = None          # the saturated v_mad_u64_u32 rate of this board, measured once per process
+        self.measured_done = False
+        self.comm_ready = False
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def make_inputs(env, n, seed, workload, scalar_bits=252, ecdh="wire"):
     """Synthetic, seeded, generated on the GPU box: P_i = r_i * B (valid subgroup points in
     non-trivial extended coordinates, produced by the engine's fixed-base kernel) and raw scalars."""
+    torch, eng = env.torch, env.eng
     rng = np.random.default_rng(seed)
 
     def scalars(bits):
@@ -121,6 +176,12 @@ def make_inputs(eng, torch, n, seed, workload, scalar_bits=252):
         if workload == "fe_invert":
             a[::1009] = 0                           # a few zeros: the reference's inverse() panics there (ok = 0, out = 0)
         return {"a": to_dev(a), "b": to_dev(b), "host": (a, b)}
+    if workload == "ecdh":
+        a, b = scalars(scalar_bits), scalars(scalar_bits)          # Alice's and Bob's secrets
+        d = {"a": to_dev(a), "b": to_dev(b), "host": (a, b)}
+        if ecdh == "reference":
+            d["base"] = to_dev(np.tile(np.array(BASEPOINT_LIMBS, dtype=np.uint64), (n, 1)))
+        return d
     P = eng.ed_mul_base(to_dev(scalars(249)))
     torch.cuda.synchronize()
     K = scalars(scalar_bits)
@@ -132,37 +193,83 @@ def make_inputs(eng, torch, n, seed, workload, scalar_bits=252):
     return d
 
 
-def cpu_baseline(workload, sample, data, n):
-    """The same operation on the host cores with the oracle (reference-shaped C restatement), on a
-    bounded sample taken from the head of the rank's own inputs.  Returns (rate, cores, seconds, units,
-    oracle results for the head of the batch) -- the results are the parity spot check."""
-    from oracle import zc_ref
-    zc_ref.build()
-    zc_ref.lib()
-    cores = zc_ref.host_threads()
-    m = min(sample, n)
-    host = lambda t: np.ascontiguousarray(t[:m].cpu().numpy()).view(np.uint64)
+def make_run(env, wl, n, scalar_bits, mode="strict", ecdh="wire"):
+    """The inputs of one workload on this rank and the function that performs ONE step of it."""
+    torch, z, eng = env.torch, env.z, env.eng
+    run = {"wl": wl, "n": n, "bits": scalar_bits, "mode": mode, "ecdh": ecdh, "st": {}}
+    data = run["data"] = make_inputs(env, n, 0x5EED0003 + env.rank, wl, scalar_bits, ecdh)
+    st = run["st"]
+    if wl == "scalar_mul":
+        st["out"] = torch.empty_like(data["P"])
+        flags = z.FAST if mode == "fast" else z.STRICT
+        run["step"] = lambda: eng.ed_scalar_mul(data["P"], data["K"], out=st["out"], flags=flags)
+    elif wl == "fe_mul":
+        run["step"] = lambda: eng.fe_mul(data["a"], data["b"])
+    elif wl == "fe_invert":
+        run["step"] = lambda: eng.fe_invert(data["a"])
+    elif wl == "msm":
+        # the whole exchange inside the library: local bucket method -> ncclAllGather of the 160-byte
+        # partial sums on the library's own RCCL communicator -> ordered fold kernel -> host
+        from dusk_zerocaf_amd import distributed as D
+        if env.backend == "nccl" or env.world == 1:
+            if not env.comm_ready:
+                D.init_library_comm(eng)
+                env.comm_ready = True
+
+            def step():
+                st["result"] = eng.msm_sharded(data["P"], data["K"])
+        else:                                       # test hook (gloo, ranks sharing a device): partials over torch.distributed
+            def step():
+                st["result"] = D.msm_sharded(data["P"], data["K"], None, engine=eng)
+        run["step"] = step
+    elif wl == "ristretto":
+        st["out"] = torch.empty_like(data["enc"])
+
+        def step():
+            st["ok"] = eng.ris_roundtrip_mul(data["enc"], data["K"], out=st["out"])[1]
+        run["step"] = step
+    elif ecdh == "wire":
+        # A = (a B).compress(), B' = (b B).compress(), S = (a * B'.decompress()).compress(), S' = (b * A.decompress()).compress()
+        def step():
+            A = eng.ris_mul_base_compress(data["a"])
+            Bp = eng.ris_mul_base_compress(data["b"])
+            S, ok1 = eng.ris_roundtrip_mul(Bp, data["a"])
+            Sp, ok2 = eng.ris_roundtrip_mul(A, data["b"])
+            st.update(A=A, Bp=Bp, S=S, Sp=Sp, ok1=ok1, ok2=ok2)
+        run["step"] = step
+    else:
+        # the reference's own ecdh_double_add: four double_and_add calls on extended points, limb-exact
+        def step():
+            A = eng.ed_scalar_mul(data["base"], data["a"])
+            Bp = eng.ed_scalar_mul(data["base"], data["b"])
+            st.update(A=A, Bp=Bp, S=eng.ed_scalar_mul(Bp, data["a"]), Sp=eng.ed_scalar_mul(A, data["b"]))
+        run["step"] = step
+    return run
+
+
+def time_run(env, run, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; HIP events on the launch stream per step."""
+    torch = env.torch
+    for _ in range(warmup):
+        run["step"]()
+    env.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    if workload == "fe_mul":
-        a, b = data["host"]
-        reps = max(1, sample // m)
-        want = None
-        for _ in range(reps):
-            want = zc_ref.mt(zc_ref.fe_mul, a[:m], b[:m])
-        m *= reps
-    elif workload == "fe_invert":
-        want = zc_ref.mt(zc_ref.fe_invert, data["host"][0][:m])
-    elif workload == "scalar_mul":
-        want = zc_ref.mt(zc_ref.ed_scalar_mul, host(data["P"]), data["host_K"][:m])
-    elif workload == "ristretto":
-        want = zc_ref.mt(zc_ref.ris_roundtrip_mul, data["enc"][:m].cpu().numpy(), data["host_K"][:m])
-    else:                                           # msm: the reference's own sum of Mul<Scalar> over the sample
-        want = zc_ref.msm_naive_mt(host(data["P"]), data["host_K"][:m])
+    for i in range(steps):
+        ev[i][0].record(env.stream)
+        run["step"]()
+        ev[i][1].record(env.stream)
+    env.barrier()
     dt = time.perf_counter() - t0
-    return m / dt, cores, dt, m, want
+    if env.world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    return dt, sum(kern_ms) / len(kern_ms) * 1e-3
 
 
-def roofline_inputs(lib_path):
+def roofline_inputs():
     """profiles/roofline_inputs.json: PMC per-unit figures, ISA shares and ubench peaks of one build."""
     path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
     if not os.path.exists(path):
@@ -174,6 +281,366 @@ def roofline_inputs(lib_path):
         return inp, "profile taken on other kernel sources (sha256 %s...) than the loaded library was built from (%s...): PMC-derived fields dropped" % (
             str(inp.get("kernel_sources_sha256"))[:12], built_from[:12])
     return inp, None
+
+
+def measured_rate(env, inp):
+    """The saturated v_mad_u64_u32 rate of THIS board in THIS run (libzc_ubench.so), once per process."""
+    if env.measured_done:
+        return dict(env.measured) if env.measured else None
+    env.measured_done = True
+    measured = None
+    try:
+        import ctypes
+        ub = ctypes.CDLL(os.path.join(os.path.dirname(env.z.LIB_PATH), "libzc_ubench.so"))
+        ub.zc_ubench_mad_u64_u32.restype = ctypes.c_double
+        ub.zc_ubench_mad_u64_u32.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+        ghz = ctypes.c_double(0.0)
+        env.torch.cuda.synchronize()
+        rate = ub.zc_ubench_mad_u64_u32(20.0, ctypes.byref(ghz))
+        if rate > 0:
+            measured = {"v_mad_u64_u32_T_lane_ops_per_s": round(rate, 2), "shader_clock_ghz": round(ghz.value, 3),
+                        "source": "libzc_ubench.so in this run: 8 waves per SIMD of independent multiply-accumulate chains, 20 ms"}
+    except OSError:
+        pass
+    if measured is None and (inp or {}).get("ubench", {}).get("v_mad_u64_u32_T_lane_ops_per_s"):
+        measured = {"v_mad_u64_u32_T_lane_ops_per_s": inp["ubench"]["v_mad_u64_u32_T_lane_ops_per_s"],
+                    "source": str(inp["ubench"].get("source")) + " (another run / board: libzc_ubench.so not built)"}
+    env.measured = measured
+    return dict(measured) if measured else None
+
+
+def roofline_for(env, run, kern_avg_s):
+    torch, eng = env.torch, env.eng
+    wl, n, mode, data = run["wl"], run["n"], run["mode"], run["data"]
+    W = WORKLOADS[wl]
+    hbm_achieved = W["bytes"] * n / kern_avg_s / 1e9
+    hbm = {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
+           "algorithmic_bytes_per_unit": W["bytes"], "traffic": None}
+    inp, stale = roofline_inputs()
+    kkey = wl if not (wl == "scalar_mul" and mode == "fast") else "scalar_mul_fast"
+    kin = (inp or {}).get("kernels", {}).get(kkey, {}) if not stale else {}
+    if kin.get("hbm_bytes_per_unit") is not None and kin.get("units_per_call") in (None, n):
+        hbm["traffic"] = round(kin["hbm_bytes_per_unit"] * n)
+        hbm["traffic_source"] = inp.get("source")
+    kernel = W["kernel"] if kkey != "scalar_mul_fast" else "k_ed_scalar_mul_fast"
+    if wl == "ecdh" and run["ecdh"] == "reference":
+        kernel = "4 x k_ed_scalar_mul_pw"
+    roofline = {"schema": ROOFLINE_SCHEMA, "bound": W["bound"], "kernel": kernel, "kernel_avg_ms": round(kern_avg_s * 1e3, 4)}
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    if W["bound"] == "hbm":
+        roofline.update({k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_unit")})
+        # the arrays of one launch against the 256 MB Infinity Cache: below it the launches of a benchmark loop find
+        # their inputs in the cache and `achieved` is cache bandwidth, not HBM
+        roofline["cache_resident"] = bool(W["bytes"] * n <= INFINITY_CACHE_BYTES)
+        if roofline["cache_resident"]:
+            roofline["note"] = "%d MB per launch fit the 256 MB Infinity Cache: cache bandwidth, not an HBM figure (the HBM line is --units 16777216)" % (W["bytes"] * n >> 20)
+        return roofline
+    if W["bound"] == "latency/occupancy":
+        # fe_invert: one division-step inversion per lane shared by c elements (Montgomery's trick); at 2^20 elements
+        # only half a wave per SIMD is resident, so neither HBM nor the multiplier is the limit
+        c = min(32, n // 65536)
+        lanes = n if c < 2 else -(-n // c)
+        roofline.update({"achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": hbm["traffic"],
+                         "algorithmic_bytes_per_unit": W["bytes"], "elements_per_lane": max(1, c), "lanes": lanes,
+                         "resident_waves_per_simd": round(lanes / 64 / (props.multi_processor_count * 4), 3),
+                         "note": "latency / occupancy bound: the figures are the HBM view for reference only; see DESIGN 4.2"})
+        return roofline
+    # peak: a v_mad_u64_u32-class wave-instruction cannot issue faster than once per 4 shader cycles per
+    # SIMD (the best ever measured on this chip is 4.4, tools/ubench/occupancy.hip), priced at the
+    # nominal clock: CUs x 4 SIMDs x 64 lanes x f_max / 4.  A hard roof; the board never holds f_max
+    # under this load, so the saturated rate MEASURED in this very run (libzc_ubench.so, same board, same
+    # thermal state, right after the headline's timed region) is reported beside it with its own fraction.
+    f_max = (getattr(props, "clock_rate", 0) or 2400000) * 1e3
+    peak = round(props.multi_processor_count * 4 * 64 * f_max / 4 / 1e12, 2)
+    measured = measured_rate(env, inp)
+    roofline.update({"achieved": None, "peak": peak, "unit": "T lane-ops/s (v_mad_u64_u32, 64 lanes per wave-instruction)",
+                     "frac": None, "traffic": hbm["traffic"], "hbm": hbm,
+                     "peak_basis": "one multiplier-class wave-instruction per 4 shader cycles per SIMD at the nominal %.1f GHz" % (f_max / 1e9),
+                     "measured_rate": measured})
+    # ---- useful work: the multiplications the algorithm needs, from this run's own inputs (no profile)
+    useful, basis, digits, plan = None, None, None, None
+    if wl == "scalar_mul" and mode == "strict":
+        evals = strict_formula_evaluations(data["host_K"])
+        useful = evals * 9 * MADS_PER_MUL
+        basis = {"formula_evaluations_per_unit": round(evals / n, 2), "multiplications_per_evaluation": 9}
+    elif wl == "scalar_mul":
+        # windowed core: 63 four-bit windows of (3 x (4S + 3M) + (4S + 4M) doublings + one 8M addition) + the 55M table
+        useful = n * (63 * WINDOW_MADS + 55 * MADS_PER_MUL)
+        basis = {"windows": 63, "v_mad_u64_u32_per_window": WINDOW_MADS}
+    elif wl == "ristretto":
+        # the same core between one decompression and one compression
+        useful = n * ROUNDTRIP_MADS
+        basis = {"windows": 63, "v_mad_u64_u32_per_window": WINDOW_MADS, "v_mad_u64_u32_per_codec": CODEC_MADS}
+    elif wl == "ecdh" and run["ecdh"] == "wire":
+        useful = n * 2 * (KEYGEN_MADS + ROUNDTRIP_MADS)
+        basis = {"per_unit": "2 key generations (33 mixed additions of 7 multiplications + one encoding) + 2 round trips (decode, windowed core, encode)",
+                 "v_mad_u64_u32_per_key_generation": KEYGEN_MADS, "v_mad_u64_u32_per_round_trip": ROUNDTRIP_MADS}
+    elif wl == "ecdh":
+        a, b = data["host"]
+        evals = 2 * (strict_formula_evaluations(a) + strict_formula_evaluations(b))
+        useful = evals * 9 * MADS_PER_MUL
+        basis = {"formula_evaluations_per_unit": round(evals / n, 2), "multiplications_per_evaluation": 9,
+                 "per_unit": "4 double_and_add calls (a B, b B, a (b B), b (a B))"}
+    elif wl == "msm":
+        # what the library itself plans for this shard (zc_msm_plan): window width, record form, multiplications per bucket addition
+        plan = eng.msm_plan(n, points_aligned16=data["P"].data_ptr() % 16 == 0)
+        if plan["window_bits"]:
+            digits, nwin = msm_nonzero_digits(data["host_K"], plan["window_bits"])
+            mpa = 7 if plan["affine"] else 8
+            useful = digits * mpa * MADS_PER_MUL            # one mixed / cached addition per non-zero digit
+            basis = {"window_bits": plan["window_bits"], "windows": nwin, "nonzero_digits_per_pair": round(digits / n, 3),
+                     "multiplications_per_bucket_addition": mpa, "plan": plan,
+                     "note": "bucket reduction, window combination and the affine normalisation are overhead, not counted"}
+    if useful is not None:
+        roofline["achieved"] = round(useful / kern_avg_s / 1e12, 3)
+        roofline["frac"] = round(useful / kern_avg_s / 1e12 / peak, 4)
+        roofline["useful"] = dict(basis, v_mad_u64_u32_lane_ops=useful)
+        if measured:
+            measured["frac"] = round(useful / kern_avg_s / 1e12 / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
+    # ---- issued work: every multiplier-class instruction (PMC x ISA share), only with a profile of THIS build at THIS size
+    if peak and kin.get("valu_insts_per_unit") and kin.get("multiplier_rate_share") and kin.get("units_per_call") in (None, n):
+        lane_ops = kin["valu_insts_per_unit"] * n * kin["multiplier_rate_share"] * 64
+        roofline["issued"] = {"achieved": round(lane_ops / kern_avg_s / 1e12, 3), "source": inp.get("source"),
+                              "valu_wave_insts_per_unit": kin["valu_insts_per_unit"], "multiplier_rate_share": kin["multiplier_rate_share"],
+                              "kernels_counted": kin.get("kernels_counted")}
+        roofline["frac_issued"] = round(roofline["issued"]["achieved"] / peak, 4)
+        if measured:
+            measured["frac_issued"] = round(roofline["issued"]["achieved"] / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
+    if wl == "msm" and digits is not None:
+        # the gathers of the bucket sums: one cached record per non-zero digit, random over the record array
+        rec = plan["record_bytes"]
+        g = {"record_bytes": rec, "records": digits, "unit": "GB/s", "peak": HBM_COPY_GBS,
+             "peak_basis": "what a device copy reaches (MI355X_MICROARCH.md); random %d-byte gathers" % rec}
+        runs = (kin.get("runs") or {}).get(str(n))
+        if runs:
+            # the bucket-sum kernel alone (its duration per step in this build's kernel trace): gathered bytes against the
+            # copy rate, and its multiplications against the multiplier roof -- the higher fraction names the bound
+            t_runs = runs["avg_ms"] * 1e-3
+            g["achieved"] = round(rec * digits / t_runs / 1e9, 1)
+            g["frac"] = round(g["achieved"] / HBM_COPY_GBS, 4)
+            g["k_msm_runs_avg_ms"] = runs["avg_ms"]
+            g["k_msm_runs_time_share"] = runs["time_share"]
+            g["k_msm_runs_multiplier_frac"] = round(useful / t_runs / 1e12 / peak, 4)
+            g["source"] = runs["source"]
+            roofline["bound"] = "gather" if g["frac"] > g["k_msm_runs_multiplier_frac"] else "valu_int_mul"
+        roofline["gather"] = g
+    if stale:
+        roofline["profile_note"] = stale
+    return roofline
+
+
+def cpu_leg(env, run, sample):
+    """The same operation on the host cores with the oracle (reference-shaped C restatement), on a
+    bounded sample taken from the head of the rank's own inputs.  Returns (rate, cores, seconds, units,
+    oracle results for the head of the batch) -- the results are the parity spot check."""
+    from oracle import zc_ref
+    zc_ref.build()
+    zc_ref.lib()
+    wl, n, data = run["wl"], run["n"], run["data"]
+    cores = zc_ref.host_threads()
+    m = min(sample, n)
+    host = lambda t: np.ascontiguousarray(t[:m].cpu().numpy()).view(np.uint64)
+    t0 = time.perf_counter()
+    if wl == "fe_mul":
+        a, b = data["host"]
+        reps = max(1, sample // m)
+        want = None
+        for _ in range(reps):
+            want = zc_ref.mt(zc_ref.fe_mul, a[:m], b[:m])
+        m *= reps
+    elif wl == "fe_invert":
+        want = zc_ref.mt(zc_ref.fe_invert, data["host"][0][:m])
+    elif wl == "scalar_mul":
+        want = zc_ref.mt(zc_ref.ed_scalar_mul, host(data["P"]), data["host_K"][:m])
+    elif wl == "ristretto":
+        want = zc_ref.mt(zc_ref.ris_roundtrip_mul, data["enc"][:m].cpu().numpy(), data["host_K"][:m])
+    elif wl == "ecdh":
+        # the reference's ecdh_double_add: key pairs with double_and_add on the basepoint, then the two shared secrets
+        a, b = data["host"][0][:m], data["host"][1][:m]
+        base = np.tile(np.array(BASEPOINT_LIMBS, dtype=np.uint64), (m, 1))
+        pa = zc_ref.mt(zc_ref.ed_scalar_mul, base, a)
+        pb = zc_ref.mt(zc_ref.ed_scalar_mul, base, b)
+        s1 = zc_ref.mt(zc_ref.ed_scalar_mul, pb, a)
+        s2 = zc_ref.mt(zc_ref.ed_scalar_mul, pa, b)
+        want = (pa, pb, s1, s2)
+    else:                                           # msm: the reference's own sum of Mul<Scalar> over the sample
+        want = zc_ref.msm_naive_mt(host(data["P"]), data["host_K"][:m])
+    dt = time.perf_counter() - t0
+    return m / dt, cores, dt, m, want
+
+
+def check_and_baseline(env, run, sample, baseline_leg, msm_fold_ok=None):
+    """Oracle results for the head of the batch against the GPU's (a mismatch aborts the run); the CPU rate beside it."""
+    from oracle import zc_ref
+    torch, eng = env.torch, env.eng
+    wl, n, data, st, mode = run["wl"], run["n"], run["data"], run["st"], run["mode"]
+    v, cores, secs, total, want = cpu_leg(env, run, sample)
+    torch.cuda.synchronize()
+    if wl == "scalar_mul":
+        k = min(len(want), n)
+        got = st["out"][:k].cpu().numpy().view(np.uint64)
+        if mode == "fast":                           # same group element: compare encodings
+            enc = lambda pts: eng.ed_compress(torch.from_numpy(np.ascontiguousarray(pts).view(np.int64)).cuda())[0].cpu().numpy()
+            checked = bool(np.array_equal(enc(got), enc(want)))
+        else:
+            checked = bool(np.array_equal(got, want))
+    elif wl == "fe_mul":
+        got = run["step"]()
+        torch.cuda.synchronize()
+        checked = bool(np.array_equal(got[:len(want)].cpu().numpy().view(np.uint64), want))
+    elif wl == "fe_invert":
+        got, gok = run["step"]()
+        torch.cuda.synchronize()
+        k = len(want[0])
+        checked = bool(np.array_equal(got[:k].cpu().numpy().view(np.uint64), want[0]) and np.array_equal(gok[:k].cpu().numpy(), want[1]))
+    elif wl == "ristretto":
+        wout, wok = want
+        k = len(wout)
+        checked = bool(np.array_equal(st["out"][:k].cpu().numpy(), wout) and np.array_equal(st["ok"][:k].cpu().numpy(), wok))
+    elif wl == "ecdh":
+        pa, pb, s1, s2 = want
+        k = len(pa)
+        if run["ecdh"] == "wire":
+            # the bytes on the wire are the reference's: compress() of its own key pairs and shared secrets; and EVERY exchange agrees
+            checked = bool(np.array_equal(st["A"][:k].cpu().numpy(), zc_ref.ris_compress(pa)) and np.array_equal(st["Bp"][:k].cpu().numpy(), zc_ref.ris_compress(pb))
+                           and np.array_equal(st["S"][:k].cpu().numpy(), zc_ref.ris_compress(s1)) and np.array_equal(st["Sp"][:k].cpu().numpy(), zc_ref.ris_compress(s2))
+                           and bool(torch.equal(st["S"], st["Sp"])) and bool(st["ok1"].all()) and bool(st["ok2"].all()))
+        else:
+            g = lambda key: st[key][:k].cpu().numpy().view(np.uint64)
+            checked = bool(np.array_equal(g("A"), pa) and np.array_equal(g("Bp"), pb) and np.array_equal(g("S"), s1) and np.array_equal(g("Sp"), s2)
+                           and bool(eng.ris_eq(st["S"], st["Sp"]).all()))
+    else:
+        # MSM: the GPU sum over the first `total` pairs against the oracle's sum of the same pairs,
+        # compared as canonical encodings (zc_msm contract: a group element)
+        sub = eng.msm(data["P"][:total], data["K"][:total])
+        checked = bool(np.array_equal(zc_ref.ed_compress(sub)[0], zc_ref.ed_compress(want)[0]) and zc_ref.ed_eq(sub, want)[0] == 1)
+        if total == n and env.world == 1:
+            checked = checked and bool(np.array_equal(zc_ref.ed_compress(st["result"])[0], zc_ref.ed_compress(want)[0]))
+        # beyond the oracle's sample the timed result was checked as the ordered fold of the shard partials
+        checked = checked and msm_fold_ok is True
+    if not checked:
+        raise SystemExit("PARITY FAILURE (%s, %d units): GPU result differs from the oracle" % (wl, n))
+    if not baseline_leg:
+        return checked, None
+    what = {"scalar_mul": "zr_ed_scalar_mul (double_and_add)", "fe_mul": "zr_fe_mul", "fe_invert": "zr_fe_inverse (Savas-Koc, field.rs:854-925)",
+            "ristretto": "zr_ris_roundtrip_mul (decompress, double_and_add, compress)",
+            "msm": "zr_msm_naive (sum of double_and_add results with the unified add)",
+            "ecdh": "4 x zr_ed_scalar_mul per unit (the reference's ecdh_double_add: two key pairs, two shared secrets)"}[wl]
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown CPU"
+    single = None
+    if cores > 1:
+        # the measured one-thread leg: the same operation on 1 / cores of the sample, one host thread
+        m1 = min(n, max(1, total // cores))
+        host1 = lambda t: np.ascontiguousarray(t[:m1].cpu().numpy()).view(np.uint64)
+        t1 = time.perf_counter()
+        if wl == "fe_mul":
+            zc_ref.fe_mul(data["host"][0][:m1], data["host"][1][:m1])
+        elif wl == "fe_invert":
+            zc_ref.fe_invert(data["host"][0][:m1])
+        elif wl == "scalar_mul":
+            zc_ref.ed_scalar_mul(host1(data["P"]), data["host_K"][:m1])
+        elif wl == "ristretto":
+            zc_ref.ris_roundtrip_mul(data["enc"][:m1].cpu().numpy(), data["host_K"][:m1])
+        elif wl == "ecdh":
+            base1 = np.tile(np.array(BASEPOINT_LIMBS, dtype=np.uint64), (m1, 1))
+            a1, b1 = data["host"][0][:m1], data["host"][1][:m1]
+            pa1, pb1 = zc_ref.ed_scalar_mul(base1, a1), zc_ref.ed_scalar_mul(base1, b1)
+            zc_ref.ed_scalar_mul(pb1, a1)
+            zc_ref.ed_scalar_mul(pa1, b1)
+        else:
+            zc_ref.msm_naive(host1(data["P"]), data["host_K"][:m1])
+        single = {"value": round(m1 / (time.perf_counter() - t1), 1), "units": m1}
+    cpu = {"value": round(v, 1), "unit": WORKLOADS[wl]["unit"], "cores": cores, "kind": "port",
+           "value_per_core": round(v / cores, 1), "value_single_core": single["value"] if single else round(v, 1),
+           "single_core_sample_units": single["units"] if single else total, "cpu_model": model,
+           "sample": "%d units from the head of the same seeded workload, %d threads, %.1f s wall (%.0f s of CPU work): %s; C "
+                     "restatement of zerocaf's u64 backend (oracle/zc_ref.c, gcc %s, built on this host), not the Rust binary"
+                     % (total, cores, secs, secs * cores, what, zc_ref.build_flags())}
+    return checked, cpu
+
+
+def default_sample(wl, world, cores):
+    per_core = {"scalar_mul": 1 << 13, "ristretto": 1 << 12, "fe_mul": 1 << 24, "fe_invert": 1 << 16, "msm": 1 << 13, "ecdh": 1 << 11}[wl]
+    return per_core * cores if world == 1 else {"fe_mul": 1 << 16, "fe_invert": 1 << 14}.get(wl, 1 << 11)   # N > 1: parity check only
+
+
+def msm_fold_check(env, run):
+    """config 5, fail closed: the timed result must be the ordered fold of the ranks' own partial sums (zc_msm_partial ->
+    torch.distributed all-gather -> zc_ed_fold_ordered: another route than the in-library exchange), and each rank's
+    partial must be the ordered fold of the partial sums of its eight contiguous sub-ranges."""
+    torch, eng, dist = env.torch, env.eng, env.dist
+    from dusk_zerocaf_amd import distributed as D
+    data, n = run["data"], run["n"]
+    part = eng.msm_partial(data["P"], data["K"])
+    per = -(-n // 8)
+    sub = torch.cat([eng.msm_partial(data["P"][lo:lo + per], data["K"][lo:lo + per]) for lo in range(0, n, per)])
+    refold = eng.ed_fold_ordered(sub)
+    torch.cuda.synchronize()
+    same = lambda a, b: bool(eng.ed_eq(a, b).cpu().numpy()[0] == 1 and
+                             np.array_equal(eng.ed_compress(a)[0].cpu().numpy(), eng.ed_compress(b)[0].cpu().numpy()))
+    ok = same(part, refold)
+    rows = part
+    if env.world > 1:
+        if env.backend == "nccl":
+            rows = D.all_gather_rows(part)
+        else:
+            rows = torch.from_numpy(D.all_gather_rows(part.cpu().numpy().view(np.uint64)).view(np.int64)).cuda()
+    total_pt = eng.ed_fold_ordered(rows)
+    timed = torch.from_numpy(np.ascontiguousarray(run["st"]["result"]).view(np.int64)).cuda()
+    ok = ok and same(total_pt, timed)
+    if env.world > 1:
+        flags = [None] * env.world
+        dist.all_gather_object(flags, bool(ok))
+        ok = all(flags)
+    if not ok:
+        raise SystemExit("PARITY FAILURE: the timed MSM result is not the ordered fold of the shard partials")
+    return ok
+
+
+def mode_label(wl, mode, ecdh):
+    return {"scalar_mul": "strict (reference formula sequence, identical X:Y:Z:T limbs)" if mode == "strict"
+                          else "FAST (non-strict extra: same group element / encodings, limbs differ by a projective factor)",
+            "fe_mul": "bit-exact canonical limbs",
+            "fe_invert": "bit-exact canonical limbs and ok mask (zero inputs)",
+            "ristretto": "bit-exact 32-byte encodings and ok mask",
+            "msm": "result compared as a group element (canonical encoding)",
+            "ecdh": "bit-exact 32-byte encodings of both public keys and both shared secrets; S == S' on every element" if ecdh == "wire"
+                    else "limb-exact public keys and shared secrets (the reference's double_and_add); S == S' on every element"}[wl]
+
+
+# the other BASELINE configs + the reference's macro-benchmark, run after the headline in the default single-GPU line:
+# (workload, units, scalar bits, timed steps, warm-up steps, oracle sample per host thread)
+SECONDARY = [("fe_mul", 1 << 24, 252, 20, 30, 1 << 14), ("fe_invert", 1 << 20, 252, 20, 5, 1 << 10), ("ristretto", 1 << 22, 252, 3, 1, 128),
+             ("msm", 1 << 21, 249, 10, 3, 256), ("ecdh", 1 << 20, 249, 3, 1, 48)]
+
+
+def secondary_runs(env):
+    out = []
+    from oracle import zc_ref
+    cores = zc_ref.host_threads()
+    for wl, n, bits, steps, warmup, per_core in SECONDARY:
+        t_all = time.perf_counter()
+        run = make_run(env, wl, n, bits)
+        dt, kern = time_run(env, run, steps, warmup)
+        fold_ok = msm_fold_check(env, run) if wl == "msm" else None
+        rf = roofline_for(env, run, kern)
+        checked, cpu = check_and_baseline(env, run, per_core * cores, True, fold_ok)
+        rec = {"workload": workload_label(wl, n, bits), "name": wl, "units": n, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+               "value": round(n * steps / dt, 1), "unit": WORKLOADS[wl]["unit"], "mode": mode_label(wl, "strict", "wire"), "roofline": rf,
+               "parity_spot_check": checked, "parity_sample_units": per_core * cores if wl != "fe_mul" else min(n, per_core * cores),
+               "cpu_value": cpu["value"] if cpu else None, "cpu_cores": cores, "wall_s": None}
+        if wl == "msm":
+            rec["msm_result_is_fold_of_shard_partials"] = fold_ok
+            rec["rccl_ranks"] = env.eng.comm_size()
+        del run
+        env.torch.cuda.empty_cache()
+        rec["wall_s"] = round(time.perf_counter() - t_all, 2)
+        out.append(rec)
+        log("secondary %s: %.4f ms per step, parity %s (%.1f s)" % (wl, rec["ms_per_step"], checked, rec["wall_s"]))
+    return out
 
 
 def main():
@@ -188,12 +655,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)         # five launches take a cold board past its clock / power transient
     ap.add_argument("--units", "--n", dest="n", type=int, default=1 << 20, help="units per GPU per step")
     ap.add_argument("--workload", default="scalar_mul", choices=list(WORKLOADS))
-    ap.add_argument("--scalar-bits", type=int, default=252, choices=[249, 252],
-                    help="252 = uniform raw 252-bit scalars (BASELINE wording, headline); 249 = the reference's Scalar::random domain")
+    ap.add_argument("--scalar-bits", type=int, default=None, choices=[249, 252],
+                    help="252 = uniform raw 252-bit scalars (BASELINE wording, headline); 249 = the reference's Scalar::random domain "
+                         "(default for msm and ecdh: SURVEY 8d config 5 / the reference's key generation)")
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"],
                     help="scalar_mul only: strict = reference formula sequence (bit-exact X:Y:Z:T limbs, the "
                          "headline); fast = windowed non-strict mode (same group element, labelled extra)")
+    ap.add_argument("--ecdh", default="wire", choices=["wire", "reference"],
+                    help="ecdh only: wire = public keys and shared secrets as 32-byte Ristretto encodings (comb key generation, fused "
+                         "round trips); reference = the reference's ecdh_double_add literally (four strict double_and_add calls)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="units for the CPU baseline / parity check (0 disables)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' lines in the default single-GPU run")
     args = ap.parse_args()
 
     import torch                                   # before the HIP library: one HIP runtime per process
@@ -223,62 +695,14 @@ def main():
     eng = z.Engine([local])
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)             # kernels and the timing events share this stream
+    env = Env(torch, z, eng, stream, rank, world, backend, dist)
     n, wl = args.n, args.workload
-    if wl == "msm" and args.scalar_bits == 252 and "--scalar-bits" not in " ".join(sys.argv):
-        args.scalar_bits = 249                      # S249 scalars
-    data = make_inputs(eng, torch, n, 0x5EED0003 + rank, wl, args.scalar_bits)
+    if args.scalar_bits is None:
+        args.scalar_bits = 249 if wl in ("msm", "ecdh") else 252
+    headline_default = (wl == "scalar_mul" and n == 1 << 20 and args.mode == "strict" and args.scalar_bits == 252)
 
-    out = None
-    if wl == "scalar_mul":
-        out = torch.empty_like(data["P"])
-        flags = z.FAST if args.mode == "fast" else z.STRICT
-        step = lambda: eng.ed_scalar_mul(data["P"], data["K"], out=out, flags=flags)
-    elif wl == "fe_mul":
-        step = lambda: eng.fe_mul(data["a"], data["b"])
-    elif wl == "fe_invert":
-        step = lambda: eng.fe_invert(data["a"])
-    elif wl == "msm":
-        # the whole exchange inside the library: local bucket method -> ncclAllGather of the 160-byte
-        # partial sums on the library's own RCCL communicator -> ordered fold kernel -> host
-        from dusk_zerocaf_amd import distributed as D
-        msm_result = []
-        if backend == "nccl" or world == 1:
-            D.init_library_comm(eng)
-
-            def step():
-                msm_result[:] = [eng.msm_sharded(data["P"], data["K"])]
-        else:                                       # test hook (gloo, ranks sharing a device): partials over torch.distributed
-            def step():
-                msm_result[:] = [D.msm_sharded(data["P"], data["K"], None, engine=eng)]
-    else:
-        out = torch.empty_like(data["enc"])
-        ok_mask = []
-
-        def step():
-            ok_mask[:] = [eng.ris_roundtrip_mul(data["enc"], data["K"], out=out)[1]]
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record(stream)
-        step()
-        ev[i][1].record(stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_avg_s = sum(kern_ms) / len(kern_ms) * 1e-3
+    run = make_run(env, wl, n, args.scalar_bits, args.mode, args.ecdh)
+    dt, kern_avg_s = time_run(env, run, args.steps, args.warmup)
 
     # what makes a multi-GPU line self-proving: which physical device every rank ran on (N distinct ones), the rank
     # count RCCL itself reports for the library's communicator, and every rank's own kernel time (a straggler shows)
@@ -301,34 +725,9 @@ def main():
     if rccl_ranks is not None and backend == "nccl" and any(d.get("rccl_ranks") != world for d in idents):
         raise SystemExit("bench.py: the library's RCCL communicator does not span %d ranks: %s" % (world, idents))
 
-    # config 5, fail closed: the timed result must be the ordered fold of the ranks' own partial sums (zc_msm_partial ->
-    # torch.distributed all-gather -> zc_ed_fold_ordered: another route than the in-library exchange), and each rank's
-    # partial must be the ordered fold of the partial sums of its eight contiguous sub-ranges
     msm_fold_ok = None
     if wl == "msm" and args.cpu_sample != 0:                 # --cpu-sample 0 skips every parity check (profiling runs)
-        part = eng.msm_partial(data["P"], data["K"])
-        per = -(-n // 8)
-        sub = torch.cat([eng.msm_partial(data["P"][lo:lo + per], data["K"][lo:lo + per]) for lo in range(0, n, per)])
-        refold = eng.ed_fold_ordered(sub)
-        torch.cuda.synchronize()
-        same = lambda a, b: bool(eng.ed_eq(a, b).cpu().numpy()[0] == 1 and
-                                 np.array_equal(eng.ed_compress(a)[0].cpu().numpy(), eng.ed_compress(b)[0].cpu().numpy()))
-        msm_fold_ok = same(part, refold)
-        rows = part
-        if world > 1:
-            if backend == "nccl":
-                rows = D.all_gather_rows(part)
-            else:
-                rows = torch.from_numpy(D.all_gather_rows(part.cpu().numpy().view(np.uint64)).view(np.int64)).cuda()
-        total_pt = eng.ed_fold_ordered(rows)
-        timed = torch.from_numpy(np.ascontiguousarray(msm_result[0]).view(np.int64)).cuda()
-        msm_fold_ok = msm_fold_ok and same(total_pt, timed)
-        if world > 1:
-            flags = [None] * world
-            dist.all_gather_object(flags, bool(msm_fold_ok))
-            msm_fold_ok = all(flags)
-        if not msm_fold_ok:
-            raise SystemExit("PARITY FAILURE: the timed MSM result is not the ordered fold of the shard partials")
+        msm_fold_ok = msm_fold_check(env, run)
 
     if rank != 0:
         if world > 1:
@@ -338,231 +737,41 @@ def main():
     W = WORKLOADS[wl]
     units = n * world * args.steps
     value = units / dt
-    hbm_achieved = W["bytes"] * n / kern_avg_s / 1e9
-    hbm = {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
-           "algorithmic_bytes_per_unit": W["bytes"], "traffic": None}
-    inp, stale = roofline_inputs(z.LIB_PATH)
-    kkey = wl if not (wl == "scalar_mul" and args.mode == "fast") else "scalar_mul_fast"
-    kin = (inp or {}).get("kernels", {}).get(kkey, {}) if not stale else {}
-    if kin.get("hbm_bytes_per_unit") is not None:
-        hbm["traffic"] = round(kin["hbm_bytes_per_unit"] * n)
-        hbm["traffic_source"] = inp.get("source")
-    roofline = {"bound": W["bound"], "kernel": W["kernel"] if kkey != "scalar_mul_fast" else "k_ed_scalar_mul_fast",
-                "kernel_avg_ms": round(kern_avg_s * 1e3, 4)}
-    props = torch.cuda.get_device_properties(torch.cuda.current_device())
-    if W["bound"] == "hbm":
-        roofline.update({k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_unit")})
-        # the arrays of one launch against the 256 MB Infinity Cache: below it the launches of a benchmark loop find
-        # their inputs in the cache and `achieved` is cache bandwidth, not HBM
-        roofline["cache_resident"] = bool(W["bytes"] * n <= INFINITY_CACHE_BYTES)
-        if roofline["cache_resident"]:
-            roofline["note"] = "%d MB per launch fit the 256 MB Infinity Cache: cache bandwidth, not an HBM figure (the HBM line is --units 16777216)" % (W["bytes"] * n >> 20)
-    elif W["bound"] == "latency/occupancy":
-        # fe_invert: one division-step inversion per lane shared by c elements (Montgomery's trick); at 2^20 elements
-        # only half a wave per SIMD is resident, so neither HBM nor the multiplier is the limit
-        c = min(32, n // 65536)
-        lanes = n if c < 2 else -(-n // c)
-        roofline.update({"achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": hbm["traffic"],
-                         "algorithmic_bytes_per_unit": W["bytes"], "elements_per_lane": max(1, c), "lanes": lanes,
-                         "resident_waves_per_simd": round(lanes / 64 / (props.multi_processor_count * 4), 3),
-                         "note": "latency / occupancy bound: the figures are the HBM view for reference only; see DESIGN 4.2"})
-    else:
-        # peak: a v_mad_u64_u32-class wave-instruction cannot issue faster than once per 4 shader cycles per
-        # SIMD (the best ever measured on this chip is 4.4, tools/ubench/occupancy.hip), priced at the
-        # nominal clock: CUs x 4 SIMDs x 64 lanes x f_max / 4.  A hard roof; the board never holds f_max
-        # under this load, so the saturated rate MEASURED in this very run (libzc_ubench.so, same board, same
-        # thermal state, right after the timed region) is reported beside it with its own fraction.
-        f_max = (getattr(props, "clock_rate", 0) or 2400000) * 1e3
-        peak = round(props.multi_processor_count * 4 * 64 * f_max / 4 / 1e12, 2)
-        measured = None
-        try:
-            import ctypes
-            ub = ctypes.CDLL(os.path.join(os.path.dirname(z.LIB_PATH), "libzc_ubench.so"))
-            ub.zc_ubench_mad_u64_u32.restype = ctypes.c_double
-            ub.zc_ubench_mad_u64_u32.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
-            ghz = ctypes.c_double(0.0)
-            torch.cuda.synchronize()
-            rate = ub.zc_ubench_mad_u64_u32(20.0, ctypes.byref(ghz))
-            if rate > 0:
-                measured = {"v_mad_u64_u32_T_lane_ops_per_s": round(rate, 2), "shader_clock_ghz": round(ghz.value, 3),
-                            "source": "libzc_ubench.so in this run: 8 waves per SIMD of independent multiply-accumulate chains, 20 ms"}
-        except OSError:
-            pass
-        if measured is None and (inp or {}).get("ubench", {}).get("v_mad_u64_u32_T_lane_ops_per_s"):
-            measured = {"v_mad_u64_u32_T_lane_ops_per_s": inp["ubench"]["v_mad_u64_u32_T_lane_ops_per_s"],
-                        "source": str(inp["ubench"].get("source")) + " (another run / board: libzc_ubench.so not built)"}
-        roofline.update({"achieved": None, "peak": peak, "unit": "T lane-ops/s (v_mad_u64_u32, 64 lanes per wave-instruction)",
-                         "frac": None, "traffic": hbm["traffic"], "hbm": hbm,
-                         "peak_basis": "one multiplier-class wave-instruction per 4 shader cycles per SIMD at the nominal %.1f GHz" % (f_max / 1e9),
-                         "measured_rate": measured})
-        # ---- useful work: the multiplications the algorithm needs, from this run's own inputs (no profile)
-        useful, basis = None, None
-        if wl == "scalar_mul" and args.mode == "strict":
-            # sum over elements of (bitlen - 1 + popcount) evaluations of the reference's addition formula,
-            # 9 multiplications of 135 v_mad_u64_u32 each
-            K = data["host_K"]
-            bits = np.zeros(n, dtype=np.int64)
-            pop = np.zeros(n, dtype=np.int64)
-            for j in range(5):
-                x = K[:, j]
-                nz = x != 0
-                bl = np.zeros(n, dtype=np.int64)
-                bl[nz] = np.floor(np.log2(x[nz].astype(np.float64))).astype(np.int64) + 1
-                bits = np.where(nz, 52 * j + bl, bits)
-                pop += np.array([bin(int(v)).count("1") for v in x]) if n <= 4096 else _popcount64(x)
-            evals = int(np.sum(np.where(bits > 0, bits - 1 + pop, 0)))
-            useful = evals * 9 * MADS_PER_MUL
-            basis = {"formula_evaluations_per_unit": round(evals / n, 2), "multiplications_per_evaluation": 9}
-        elif wl == "scalar_mul":
-            # windowed core: 63 four-bit windows of (3 x (4S + 3M) + (4S + 4M) doublings + one 8M addition) + the 55M table
-            useful = n * (63 * (4 * (4 * 99 + 3 * 135) + 135 + 8 * 135) + 55 * 135)
-            basis = {"windows": 63, "v_mad_u64_u32_per_window": 4 * (4 * 99 + 3 * 135) + 135 + 8 * 135}
-        elif wl == "ristretto":
-            # the same core between one decompression and one compression (one (p-5)/8 power each: ~250 squarings + ~36
-            # multiplications, + ~25 multiplications of glue)
-            codec = 250 * 99 + 61 * 135
-            useful = n * (63 * (4 * (4 * 99 + 3 * 135) + 135 + 8 * 135) + 55 * 135 + 2 * codec)
-            basis = {"windows": 63, "v_mad_u64_u32_per_window": 4 * (4 * 99 + 3 * 135) + 135 + 8 * 135, "v_mad_u64_u32_per_codec": codec}
-        elif wl == "msm":
-            c_bits = msm_window_bits(n)
-            digits, nwin = msm_nonzero_digits(data["host_K"], c_bits)
-            useful = digits * 7 * MADS_PER_MUL               # one 7-multiplication mixed addition per non-zero digit
-            basis = {"window_bits": c_bits, "windows": nwin, "nonzero_digits_per_pair": round(digits / n, 3), "multiplications_per_bucket_addition": 7,
-                     "note": "bucket reduction, window combination and the affine normalisation are overhead, not counted"}
-        if useful is not None:
-            roofline["achieved"] = round(useful / kern_avg_s / 1e12, 3)
-            roofline["frac"] = round(useful / kern_avg_s / 1e12 / peak, 4)
-            roofline["useful"] = dict(basis, v_mad_u64_u32_lane_ops=useful)
-            if measured:
-                measured["frac"] = round(useful / kern_avg_s / 1e12 / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
-        # ---- issued work: every multiplier-class instruction (PMC x ISA share), only with a profile of THIS build
-        if peak and kin.get("valu_insts_per_unit") and kin.get("multiplier_rate_share"):
-            lane_ops = kin["valu_insts_per_unit"] * n * kin["multiplier_rate_share"] * 64
-            roofline["issued"] = {"achieved": round(lane_ops / kern_avg_s / 1e12, 3), "source": inp.get("source"),
-                                  "valu_wave_insts_per_unit": kin["valu_insts_per_unit"], "multiplier_rate_share": kin["multiplier_rate_share"],
-                                  "kernels_counted": kin.get("kernels_counted")}
-            roofline["frac_issued"] = round(roofline["issued"]["achieved"] / peak, 4)
-            if measured:
-                measured["frac_issued"] = round(roofline["issued"]["achieved"] / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
-        if wl == "msm":
-            # the gathers of the bucket sums: one cached record per non-zero digit, random over the record array
-            rec = 96 if n >= (1 << 17) else 128
-            g = {"record_bytes": rec, "records": basis["nonzero_digits_per_pair"] * n, "unit": "GB/s", "peak": HBM_COPY_GBS,
-                 "peak_basis": "what a device copy reaches (MI355X_MICROARCH.md); random %d-byte gathers" % rec}
-            runs = (kin.get("runs") or {}).get(str(n))
-            if runs:
-                # the bucket-sum kernel alone (its average duration in this build's kernel trace): gathered bytes against the
-                # copy rate, and its multiplications against the multiplier roof -- the higher fraction names the bound
-                t_runs = runs["avg_ms"] * 1e-3
-                g["achieved"] = round(rec * digits / t_runs / 1e9, 1)
-                g["frac"] = round(g["achieved"] / HBM_COPY_GBS, 4)
-                g["k_msm_runs_avg_ms"] = runs["avg_ms"]
-                g["k_msm_runs_time_share"] = runs["time_share"]
-                g["k_msm_runs_multiplier_frac"] = round(useful / t_runs / 1e12 / peak, 4)
-                g["source"] = runs["source"]
-                roofline["bound"] = "gather" if g["frac"] > g["k_msm_runs_multiplier_frac"] else "valu_int_mul"
-            roofline["gather"] = g
-        if stale:
-            roofline["profile_note"] = stale
+    roofline = roofline_for(env, run, kern_avg_s)
 
     cpu, checked = None, None
     sample = args.cpu_sample
     baseline_leg = world == 1 or sample > 0         # the CPU baseline is reported at N = 1 (or when asked for)
     if sample < 0:
         from oracle import zc_ref as _z
-        per_core = {"scalar_mul": 1 << 13, "ristretto": 1 << 12, "fe_mul": 1 << 24, "fe_invert": 1 << 16, "msm": 1 << 13}[wl]
-        sample = per_core * _z.host_threads() if world == 1 else {"fe_mul": 1 << 16, "fe_invert": 1 << 14}.get(wl, 1 << 11)   # N > 1: parity check only
+        sample = default_sample(wl, world, _z.host_threads())
     if sample:
-        from oracle import zc_ref
-        v, cores, secs, total, want = cpu_baseline(wl, sample, data, n)
-        k = 0 if wl == "msm" else min(len(want[0] if wl in ("ristretto", "fe_invert") else want), n)
-        if wl == "scalar_mul":
-            torch.cuda.synchronize()
-            got = out[:k].cpu().numpy().view(np.uint64)
-            if args.mode == "fast":                  # same group element: compare encodings
-                enc = lambda pts: eng.ed_compress(torch.from_numpy(np.ascontiguousarray(pts).view(np.int64)).cuda())[0].cpu().numpy()
-                checked = bool(np.array_equal(enc(got), enc(want)))
-            else:
-                checked = bool(np.array_equal(got, want))
-        elif wl == "fe_mul":
-            got = step()
-            torch.cuda.synchronize()
-            checked = bool(np.array_equal(got[:k].cpu().numpy().view(np.uint64), want))
-        elif wl == "fe_invert":
-            got, gok = step()
-            torch.cuda.synchronize()
-            checked = bool(np.array_equal(got[:k].cpu().numpy().view(np.uint64), want[0]) and np.array_equal(gok[:k].cpu().numpy(), want[1]))
-        elif wl == "ristretto":
-            torch.cuda.synchronize()
-            wout, wok = want
-            checked = bool(np.array_equal(out[:k].cpu().numpy(), wout) and np.array_equal(ok_mask[0][:k].cpu().numpy(), wok))
-        else:
-            # MSM: the GPU sum over the first `total` pairs against the oracle's sum of the same pairs,
-            # compared as canonical encodings (zc_msm contract: a group element)
-            sub = eng.msm(data["P"][:total], data["K"][:total])
-            checked = bool(np.array_equal(zc_ref.ed_compress(sub)[0], zc_ref.ed_compress(want)[0]) and zc_ref.ed_eq(sub, want)[0] == 1)
-            if total == n and world == 1:
-                checked = checked and bool(np.array_equal(zc_ref.ed_compress(msm_result[0])[0], zc_ref.ed_compress(want)[0]))
-            # beyond the oracle's sample the timed result was checked above as the ordered fold of the shard partials
-            checked = checked and msm_fold_ok is True
-        if not checked:
-            raise SystemExit("PARITY FAILURE: GPU result differs from the oracle")
-        what = {"scalar_mul": "zr_ed_scalar_mul (double_and_add)", "fe_mul": "zr_fe_mul", "fe_invert": "zr_fe_inverse (Savas-Koc, field.rs:854-925)", "ristretto": "zr_ris_roundtrip_mul (decompress, double_and_add, compress)",
-                "msm": "zr_msm_naive (sum of double_and_add results with the unified add)"}[wl]
-        try:
-            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-        except Exception:
-            model = "unknown CPU"
-        single = None
-        if baseline_leg and cores > 1:
-            # the measured one-thread leg: the same operation on 1 / cores of the sample, one host thread
-            m1 = min(n, max(1, total // cores))
-            host1 = lambda t: np.ascontiguousarray(t[:m1].cpu().numpy()).view(np.uint64)
-            t1 = time.perf_counter()
-            if wl == "fe_mul":
-                zc_ref.fe_mul(data["host"][0][:m1], data["host"][1][:m1])
-            elif wl == "fe_invert":
-                zc_ref.fe_invert(data["host"][0][:m1])
-            elif wl == "scalar_mul":
-                zc_ref.ed_scalar_mul(host1(data["P"]), data["host_K"][:m1])
-            elif wl == "ristretto":
-                zc_ref.ris_roundtrip_mul(data["enc"][:m1].cpu().numpy(), data["host_K"][:m1])
-            else:
-                zc_ref.msm_naive(host1(data["P"]), data["host_K"][:m1])
-            single = {"value": round(m1 / (time.perf_counter() - t1), 1), "units": m1}
-        cpu = None if not baseline_leg else {"value": round(v, 1), "unit": W["unit"], "cores": cores, "kind": "port",
-               "value_per_core": round(v / cores, 1), "value_single_core": single["value"] if single else round(v, 1),
-               "single_core_sample_units": single["units"] if single else total, "cpu_model": model,
-               "sample": "%d units from the head of the same seeded workload, %d threads, %.1f s wall (%.0f s of CPU work): %s; C "
-                         "restatement of zerocaf's u64 backend (oracle/zc_ref.c, gcc -O3), not the Rust binary"
-                         % (total, cores, secs, secs * cores, what)}
+        checked, cpu = check_and_baseline(env, run, sample, baseline_leg, msm_fold_ok)
+
+    secondary = None
+    if headline_default and world == 1 and not args.no_secondary and args.cpu_sample != 0:
+        del run
+        torch.cuda.empty_cache()
+        secondary = secondary_runs(env)
 
     metric = {"scalar_mul": "%d-bit Edwards variable-base scalar-muls/sec (batched, %s)" % (
                   args.scalar_bits, "strict bit-exact mode" if args.mode == "strict" else "FAST non-strict mode"),
               "msm": "MSM point-scalar pairs/sec (bucket method per GPU, in-library RCCL all-gather + ordered fold across GPUs)",
               "ristretto": "Ristretto decompress -> scalar-mul -> compress round trips/sec (fused, bit-exact encodings)",
               "fe_mul": "FieldElement multiplications/sec (batched, bit-exact canonical limbs)",
-              "fe_invert": "FieldElement inversions/sec (batched, bit-exact canonical limbs)"}[wl]
+              "fe_invert": "FieldElement inversions/sec (batched, bit-exact canonical limbs)",
+              "ecdh": "ECDH exchanges/sec (two key generations + two shared secrets each; the reference's macro-benchmark)"}[wl]
     line = {
         "metric": metric, "value": round(value, 1), "unit": W["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64 (nine 29-bit limbs in u32 registers, 64-bit multiply-accumulate columns)", "data": "synthetic",
-        "config": {"workload": {"scalar_mul": "2^20 EdwardsPoint variable-base scalar-mul, random %d-bit scalars (BASELINE configs[2])" % args.scalar_bits,
-                                "fe_mul": "2^20 FieldElement mul (BASELINE configs[1])",
-                                "fe_invert": "2^20 FieldElement invert (BASELINE configs[1]); division-step inversion shared by up to 32 elements per lane",
-                                "ristretto": "Ristretto decompress->scalar-mul->compress, random %d-bit scalars, ~1%% undecodable inputs (BASELINE configs[3] shape)" % args.scalar_bits,
-                                "msm": "Pippenger MSM, %d-bit scalars, one shard per GPU (BASELINE configs[4] shape)" % args.scalar_bits}[wl],
+        "config": {"workload": workload_label(wl, n, args.scalar_bits, args.ecdh),
                    "units_per_gpu_per_step": n,
                    "sharding": "contiguous ranges; ncclAllGather of one 160-byte partial sum per rank inside libzerocaf_hip.so + ordered fold kernel"
                                if wl == "msm" else "contiguous ranges, no collective",
-                   "mode": {"scalar_mul": "strict (reference formula sequence, identical X:Y:Z:T limbs)" if args.mode == "strict"
-                                          else "FAST (non-strict extra: same group element / encodings, limbs differ by a projective factor)",
-                            "fe_mul": "bit-exact canonical limbs",
-                            "fe_invert": "bit-exact canonical limbs and ok mask (zero inputs)",
-                            "ristretto": "bit-exact 32-byte encodings and ok mask",
-                            "msm": "result compared as a group element (canonical encoding)"}[wl]},
+                   "mode": mode_label(wl, args.mode, args.ecdh)},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_spot_check": checked,
@@ -573,6 +782,8 @@ def main():
     if wl == "msm":
         line["rccl_ranks"] = rccl_ranks                      # ncclCommCount of the library's own communicator (None: gloo test hook)
         line["msm_result_is_fold_of_shard_partials"] = msm_fold_ok
+    if secondary is not None:
+        line["secondary"] = secondary
     os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()

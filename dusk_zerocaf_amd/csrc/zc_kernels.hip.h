@@ -36,6 +36,18 @@ ZC_DI int wave_max_small(int v)
     return r;
 }
 
+// the same for -1 <= v < 511 (the w-NAF's digit positions run to 255)
+ZC_DI int wave_max_9bit(int v)
+{
+    int r = -1;
+#pragma unroll
+    for (int b = 8; b >= 0; b--) {
+        const int t = r + (1 << b);
+        if (__ballot(v >= t) != 0) r = t;
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------ radix-2^52 add/sub
 // Add/Sub/Neg are carry/borrow chains over the reference's own limbs
 // (field.rs:191-240, scalar.rs:184-237); they are done directly in radix 2^52 so the
@@ -1075,7 +1087,7 @@ ZC_KERNEL_2W void k_ed_mul_base_wnaf(const u64* k, u32 width, u64* out, const u3
         if (ki != 0) top = d;
     }
     if (!valid) top = -1;
-    top = wave_max_small(top);
+    top = wave_max_9bit(top);
     pt Q = pt_identity();
     for (int d = top; d >= 0; d--) {
         if (d != top) Q = pt_double_fast<true>(Q);          // doubling the identity changes nothing: the leading one is skipped

@@ -298,22 +298,33 @@ ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 
 #define ZC_MSM_RUN_BLOCK 256   // threads per workgroup of k_msm_runs (its waves never synchronise: A/B knob)
 #endif
 constexpr int MSM_RUN_BLOCK = ZC_MSM_RUN_BLOCK;
+// Everything behind the bucket sums is a chain of dependent point operations on few waves.  When the windows go through
+// the pipeline in groups (below, and zerocaf_hip.hip: msm_on_device) a group's chain runs BESIDE the bucket sums of the groups below it, whose
+// four waves per SIMD would otherwise win every issue slot (older waves first): the chain's kernels raise their wave
+// priority, so that the arbiter serves them first -- they need few slots, but they need them now.
+ZC_DI void msm_tail_priority() { __builtin_amdgcn_s_setprio(3); }
+// WINDOW GROUPS.  A launch covers one group of windows: a part of the sorted list (the list is ordered by window; where a
+// window starts is known on the device only -- the key sort's last scan table, zc_sort.hip.h: msm_sort_slot).  Lane j owns
+// the run [*range_lo + j T, *range_lo + (j + 1) T) cut at *range_end (nullptr: the whole list [0, len)); the host sizes the
+// launch for the longest the part can be, lanes behind its end idle.  The neighbours a lane looks at for its open ends may
+// lie in another group (another window: another key).  `sj`: the lane's number in the edge arrays (groups share them).
 template <bool AFFINE>
 ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict__ recs, u32 len, u32 T, u32 nbuckets,
-                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 j, u32 sj)
 {
     constexpr int PIECES = AFFINE ? 6 : 8;                     // 16-byte pieces of a cached record
     __shared__ uint4 stage[PIECES * MSM_RUN_BLOCK];
     const int lane = threadIdx.x & 63;
     uint4* base = stage + (threadIdx.x >> 6) * (PIECES * 64);
-    const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
-    const u64 lo64 = (u64)j * T;
-    if (lo64 >= len) return;
-    const u32 lo = (u32)lo64;
-    const u32 hi = (len - lo > T) ? lo + T : len;
     const u32 none = 0xFFFFFFFFu;
-    next_keys[2 * (size_t)j] = none;                           // this lane's two edge slots: unused until msm_flush says otherwise
-    next_keys[2 * (size_t)j + 1] = none;
+    next_keys[2 * (size_t)sj] = none;                          // this lane's two edge slots (lane sj of the edge arrays): unused until msm_flush says otherwise
+    next_keys[2 * (size_t)sj + 1] = none;
+    const u32 first_pos = range_lo ? *range_lo : 0u;
+    const u32 end_pos = range_end ? *range_end : len;
+    const u64 lo64 = (u64)first_pos + (u64)j * T;
+    if (lo64 >= end_pos) return;
+    const u32 lo = (u32)lo64;
+    const u32 hi = (end_pos - lo > T) ? lo + T : end_pos;
     const uint2 cur = pairs[lo];
     u32 cur_key = cur.x;
     if (cur_key >= nbuckets) return;                           // zero digits sort behind every bucket: nothing to add
@@ -346,7 +357,7 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
         acc = pt_add_cached<ZC_MSM_ACC_ILP, AFFINE>(acc, niels_cond_neg((e & 1) != 0, q0));
         const bool last = e + 1 == hi;
         if (last || (e & 31) == 31) {
-            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, sj, nbuckets, buckets_raw, present, next_keys, next_recs);
             acc = pt_identity();
             first = false;
         }
@@ -374,7 +385,7 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
         acc = pt_add_cached<ZC_MSM_ACC_ILP, AFFINE>(acc, niels_cond_neg(neg, q));
         const bool last = e + 1 == hi;
         if (last || knext != cur_key) {                        // the segment ends with this entry
-            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
+            msm_flush(cur_key, acc, first, last, prev_key, next_key, sj, nbuckets, buckets_raw, present, next_keys, next_recs);
             acc = pt_identity();
             first = false;
             cur_key = knext;
@@ -384,15 +395,17 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
 }
 extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0)
 {
-    msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs);
+    const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
+    if (j < nlanes) msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j);
 }
 extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs_affine(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0)
 {
-    msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs);
+    const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
+    if (j < nlanes) msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j);
 }
 
 // Levels >= 1: the edge list of the level above (raw 144-byte records in list order, sentinel keys in
@@ -403,6 +416,7 @@ void k_msm_runs_affine(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 
 ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
                                 u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
 {
+    msm_tail_priority();
     const u32 j = blockIdx.x * ZC_BLOCK + threadIdx.x;
     const u64 lo64 = j ? (u64)j * T + 1 : 0;
     if (lo64 >= len) return;
@@ -412,6 +426,20 @@ ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T
     const u64 hi64 = (u64)(j + 1) * T + 1;
     const u32 hi = hi64 < len ? (u32)hi64 : len;
     const u32 none = 0xFFFFFFFFu;
+    {
+        // Most runs of most levels hold unused slots only (a uniform batch closes nearly every cut bucket at level 1): look at
+        // the run's keys eight at a time -- independent loads, one wait -- before walking it entry by entry (a lane that walks
+        // eight sentinel keys one dependent load after the other takes 40 us; measured on the levels behind the first).
+        bool any = false;
+        for (u32 b = lo; b < hi; b += 8) {
+            u32 kk[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) kk[i] = b + i < hi ? keys[b + i] : none;
+#pragma unroll
+            for (int i = 0; i < 8; i++) any = any || kk[i] < nbuckets;
+        }
+        if (!any) return;
+    }
     const u32 prev_key = lo > 0 ? keys[lo - 1] : none;
     const u32 next_key = hi < len ? keys[hi] : none;
     pt acc = pt_identity();
@@ -434,24 +462,73 @@ ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T
 // index b of a window holds the digit magnitude b + 1):
 //   acc = sum_j B_{first+j},  sum = sum_j (j + 1) B_{first+j}   (running sums from the top bucket down)
 // so that  sum_j (first' + j + 1) B_{first+j} = sum + first' * acc  with first' = first mod 2^(c-1).
-// Emits sum, acc and the scalar first'.
-ZC_KERNEL void k_msm_segments(const u32* buckets_raw, const uint8_t* present, u64* seg_sum, u64* seg_acc, u64* seg_scalar, size_t nseg_total, int c, int seg)
+// The lane then finishes its segment on the spot: out = sum + first' * acc, the product by the reference's own
+// LSB-first double-and-add on the unified addition (scalar_mul_unified; first' < 2^(c-1) is one word) -- no round trip
+// through memory and no further launches between the running sums and the fold (rounds 1-3: k_msm_segments ->
+// k_ed_scalar_mul_small -> k_ed_add, three launches and two canonical store / load pairs per segment).
+// The arrays are the launch's own part of the bucket array (a window group starts at a window boundary).
+ZC_KERNEL void k_msm_segments(const u32* buckets_raw, const uint8_t* present, u64* seg_out, size_t nseg_total, int c, int seg)
 {
+    __shared__ u32 sk[ZC_BLOCK];
+    msm_tail_priority();
     const size_t s = gid();
-    if (s >= nseg_total) return;
-    const size_t first = s * (size_t)seg;                 // global bucket index of the segment start
+    const bool valid = s < nseg_total;
+    const size_t first = (valid ? s : 0) * (size_t)seg;   // bucket index of the segment start (relative to a window boundary)
     pt acc = pt_identity(), sum = pt_identity();
+    if (valid) {
+        for (int j = seg - 1; j >= 0; j--) {
+            pt b = pt_identity();
+            if (present[first + j]) b = pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j));
+            acc = pt_add<true>(acc, b);
+            sum = pt_add<true>(sum, acc);
+        }
+    }
+    const u32 k = valid ? (u32)(first & (((size_t)1 << (c - 1)) - 1)) : 0u;
+    sk[threadIdx.x] = k;
+    const int nbits = k ? 32 - __builtin_clz(k) : 0;
+    const pt prod = scalar_mul_unified<true>(acc, sk + threadIdx.x, ZC_BLOCK, nbits);     // nbits = 0: the identity
+    if (valid) pt_store(seg_out + 20 * s, pt_add<true>(sum, prod));
+}
+
+// The same with four lanes per segment (ptm_add_quad, zc_quad.hip.h: three multiplication latencies per addition instead
+// of nine, the same field values): for launches of so few segments that every SIMD holds a single wave anyway -- the
+// lowest window group, whose chain nothing hides, and small shards.
+ZC_KERNEL void k_msm_segments_quad(const u32* buckets_raw, const uint8_t* present, u64* seg_out, size_t nseg_total, int c, int seg)
+{
+    msm_tail_priority();
+    const int role = threadIdx.x & 3;
+    const size_t s = (size_t)blockIdx.x * (ZC_BLOCK / 4) + (threadIdx.x >> 2);
+    const bool valid = s < nseg_total;
+    const size_t first = (valid ? s : 0) * (size_t)seg;
+    const ptm ident = ptm_from_pt(pt_identity());
+    ptm acc = ident, sum = ident;
     for (int j = seg - 1; j >= 0; j--) {
         pt b = pt_identity();
-        if (present[first + j]) b = pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j));
-        acc = pt_add<true>(acc, b);
-        sum = pt_add<true>(sum, acc);
+        if (valid && present[first + j]) b = pt_load_raw(buckets_raw + MSM_RAW_WORDS * (first + j));
+        acc = ptm_add_quad(acc, ptm_from_pt(b), role);
+        sum = ptm_add_quad(sum, acc, role);
     }
-    pt_store(seg_sum + 20 * s, sum);
-    pt_store(seg_acc + 20 * s, acc);
-    u64* k = seg_scalar + 5 * s;
-    k[0] = (u64)(first & (((size_t)1 << (c - 1)) - 1));
-    k[1] = 0; k[2] = 0; k[3] = 0; k[4] = 0;
+    const u32 k = valid ? (u32)(first & (((size_t)1 << (c - 1)) - 1)) : 0u;
+    const int nbits = k ? 32 - __builtin_clz(k) : 0;
+    ptm N = acc, Q = ident;                                  // k * acc: the unified-step loop of scalar_mul_unified, quad-uniform
+    int pos = 0;
+    bool pend = (k & 1) != 0;
+    bool active = nbits > 0;
+    while (active) {
+        const ptm lhs = ptm_select(pend, Q, N);
+        const ptm r = ptm_add_quad(lhs, N, role);
+        if (pend) {
+            Q = r;
+            pend = false;
+            active = pos < nbits - 1;
+        } else {
+            N = r;
+            pos++;
+            pend = ((k >> pos) & 1) != 0;
+        }
+    }
+    sum = ptm_add_quad(sum, Q, role);
+    if (valid && role == 0) pt_store(seg_out + 20 * s, ptm_to_pt(sum));
 }
 
 // One workgroup folds `g` consecutive points (g a power of two, 2 <= g <= 512) into one: pairs on
@@ -461,6 +538,7 @@ ZC_KERNEL void k_msm_segments(const u32* buckets_raw, const uint8_t* present, u6
 ZC_KERNEL void k_msm_fold_groups(const u64* in, u64* out, u32 g)
 {
     __shared__ uint4 sraw[9 * ZC_BLOCK];
+    msm_tail_priority();
     u32* mine = reinterpret_cast<u32*>(sraw) + MSM_RAW_WORDS * threadIdx.x;
     const u32 t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * g;
@@ -501,23 +579,37 @@ ZC_DI pt pt_double_quad(const pt& p, int role)
     r.T = quad_bcast<3>(m);
     return r;
 }
-// one wave; windows[w] = S_w (W points); out = sum_w 2^(c w) S_w
-ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c)
+// one wave; windows[w] = S_w (W points); out = 2^(c W) * carry + sum_w 2^(c w) S_w  (carry: nullptr = none).
+// Window groups: Horner's rule runs top window first across the groups -- the group below continues where the group above
+// stopped (`carry` = that group's result), so no group pays doublings for windows that are not its own.
+// Leading terms that are the literal identity (0 : y : y : 0) -- the windows above the longest scalar of the batch -- need no
+// doublings: the rule starts at the first non-trivial one.
+ZC_DI bool msm_is_literal_identity(const u64* s)
 {
-    const int role = threadIdx.x & 3;
-    // leading windows whose sum is the literal identity (0 : y : y : 0) -- the windows above the longest
-    // scalar of the batch -- need no doublings: Horner's rule starts at the first non-trivial one
-    for (; W > 1; W--) {
-        const u64* s = windows + 20 * (size_t)(W - 1);
-        u64 nz = 0;
+    u64 nz = 0;
 #pragma unroll
-        for (int j = 0; j < 5; j++) nz |= s[j] | s[15 + j] | (s[5 + j] ^ s[10 + j]);
-        if (nz) break;
+    for (int j = 0; j < 5; j++) nz |= s[j] | s[15 + j] | (s[5 + j] ^ s[10 + j]);
+    return nz == 0;
+}
+ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c, const u64* carry)
+{
+    msm_tail_priority();
+    const int role = threadIdx.x & 3;
+    pt Q = pt_identity();
+    bool started = false;
+    if (carry && !msm_is_literal_identity(carry)) {
+        Q = pt_load(carry);
+        started = true;
     }
-    pt Q = pt_load(windows + 20 * (size_t)(W - 1));
-    for (int w = W - 2; w >= 0; w--) {
-        for (int i = 0; i < c; i++) Q = pt_double_quad(Q, role);
-        Q = pt_add<true>(Q, pt_load(windows + 20 * (size_t)w));
+    for (int w = W - 1; w >= 0; w--) {
+        const u64* sw = windows + 20 * (size_t)w;
+        if (started)
+            for (int i = 0; i < c; i++) Q = pt_double_quad(Q, role);
+        if (!msm_is_literal_identity(sw)) {
+            const pt S = pt_load(sw);
+            Q = started ? pt_add<true>(Q, S) : S;
+            started = true;
+        }
     }
     if (threadIdx.x == 0) pt_store(out, Q);
 }

@@ -66,6 +66,13 @@ struct Tuning {
     int msm_fork = -1;               // ZC_MSM_FORK=0/1
     int msm_affine_chunk = 0;        // ZC_MSM_AFFINE_CHUNK=c (1..64)
     int msm_seg = 0;                 // ZC_MSM_SEG=s (power of two, 2..256)
+    int msm_groups[4] = {0, 0, 0, 0};   // ZC_MSM_GROUPS="a,b[,c[,d]]": windows per group, top group first ("1" = one group)
+    int msm_ngroups = 0;
+    int msm_tail_prio = -1;          // ZC_MSM_TAIL_PRIO=0/1: the groups' tails on high-priority streams (default 1)
+    long msm_seg_quad = -1;          // ZC_MSM_SEG_QUAD=s: four lanes per segment in launches of at most s segments (0: never)
+    long msm_group_lanes = 0;        // ZC_MSM_GROUP_LANES=l: lanes a window group's bucket-sum launch keeps busy (log2, 15..22)
+    int msm_tail_side = -1;          // ZC_MSM_TAIL_SIDE=0: the groups' chains on the caller's stream, one after the other (A/B: no overlap)
+    long msm_group_wgs = -1;         // ZC_MSM_GROUP_WGS=k: workgroups per CU of the bucket-sum launches that run beside a tail (0: no limit)
 #ifdef ZC_TEST_HOOKS
     bool test_ring_poison = false;   // ZC_TEST_RING_POISON: pretend a wave of every windowed-core launch gave up
     unsigned test_ring_spins = 0;    // ZC_TEST_RING_SPINS=b: waves give up after 2^b polls (default 22, about 4 s)
@@ -101,6 +108,21 @@ Tuning tuning_from_env()
         const long f = env_long("ZC_MSM_SEG", 2, 256, 0);
         if (f && (f & (f - 1)) == 0) t.msm_seg = (int)f;
     }
+    if (const char* e = getenv("ZC_MSM_GROUPS")) {
+        for (const char* q = e; *q && t.msm_ngroups < 4;) {
+            char* end = nullptr;
+            const long x = strtol(q, &end, 10);
+            if (end == q || x < 1 || x > 64) break;
+            t.msm_groups[t.msm_ngroups++] = (int)x;
+            if (*end != ',') break;
+            q = end + 1;
+        }
+    }
+    t.msm_tail_prio = (int)env_long("ZC_MSM_TAIL_PRIO", 0, 1, -1);
+    t.msm_seg_quad = env_long("ZC_MSM_SEG_QUAD", 0, 1 << 24, -1);
+    t.msm_group_lanes = env_long("ZC_MSM_GROUP_LANES", 15, 22, 0);
+    t.msm_group_wgs = env_long("ZC_MSM_GROUP_WGS", 0, 8, -1);
+    t.msm_tail_side = (int)env_long("ZC_MSM_TAIL_SIDE", 0, 1, -1);
 #ifdef ZC_TEST_HOOKS
     t.test_ring_poison = getenv("ZC_TEST_RING_POISON") != nullptr;
     t.test_ring_spins = (unsigned)env_long("ZC_TEST_RING_SPINS", 1, 30, 0);
@@ -141,6 +163,8 @@ struct DevState {
     hipStream_t aux = nullptr;          // MSM: the point normalisation runs beside the key sort (other priority than `stream`:
                                         // two streams of one priority share a hardware queue here and run one after the other)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t grp[3] = {};            // MSM window groups: the tails of the groups above the lowest one (highest priority)
+    hipEvent_t ev_grp_go[3] = {}, ev_grp_done[3] = {};
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -675,8 +699,20 @@ struct MsmPlan {
     int T = 0, TE = 0;             // run lengths of the segmented reduction: level 0, deeper levels
     int seg = 0;                   // buckets per reduction segment
     size_t m = 0, nb = 0, nseg = 0;   // list entries (n W), buckets, segments
+    int G = 1;                     // window groups, top windows first: gw[g] windows, run length gT[g]
+    int gw[4] = {0, 0, 0, 0}, gT[4] = {0, 0, 0, 0};
     MsmSortPlan sort;
 };
+// Run length of the bucket-sum kernel for a list of m entries: 128 entries per lane, fewer when the list is short (keep
+// >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper levels.
+// Measured (tools/quick_bench.py, ZC_MSM_RUN / ZC_MSM_RUN_EDGES): 2^20 pairs T = 32 / 128 / 256: 2.90 / 2.83 / 3.12 ms;
+// 2^21: 4.67 / 4.48 / 4.52; edge runs of 8 / 16 / 32: 2^21 4.44 / 4.53 / 4.63 ms.  Round 3, 2^24 pairs (2^27.9
+// entries): T = 128 / 256: 21.94 / 21.53 ms -- half the edges for the deeper levels.
+inline int msm_run_length(size_t m, const Tuning& tune, int lanes_log2 = 17)
+{
+    if (tune.msm_run) return tune.msm_run;                // T >= 4: every level shortens the list (2 ceil(len / T) < len)
+    return m >= ((size_t)1 << 27) ? 256 : (int)std::min<size_t>(128, std::max<size_t>(8, m >> lanes_log2));
+}
 MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
 {
     MsmPlan p;
@@ -690,15 +726,33 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     p.nseg = p.nb / (size_t)p.seg;
     p.sort = msm_sort_plan(cnt, p.c, p.W, tune);
     p.affine = msm_affine(cnt, tune) && points_aligned16;  // the normalisation moves the point records with 16-byte loads
-    // run length of the segmented reduction: 128 entries per lane, fewer when the list is short (keep
-    // >= 2^17 lanes = two waves per SIMD busy); longer runs leave fewer edges (2 per run) for the deeper
-    // levels.  Measured (tools/quick_bench.py, ZC_MSM_RUN / ZC_MSM_RUN_EDGES): 2^20 pairs T = 32 / 128 / 256:
-    // 2.90 / 2.83 / 3.12 ms; 2^21: 4.67 / 4.48 / 4.52; edge runs of 8 / 16 / 32: 2^21 4.44 / 4.53 / 4.63 ms.
-    // Round 3, 2^24 pairs (2^27.9 entries): T = 128 / 256: 21.94 / 21.53 ms -- half the edges for the deeper levels.
-    p.T = p.m >= ((size_t)1 << 27) ? 256 : (int)std::min<size_t>(128, std::max<size_t>(8, p.m >> 17));
+    p.T = msm_run_length(p.m, tune);
     p.TE = 8;                                             // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
-    if (tune.msm_run) p.T = tune.msm_run;                 // T >= 4: every level shortens the list (2 ceil(len / T) < len)
     if (tune.msm_run_edges) p.TE = tune.msm_run_edges & ~1;
+    // Window groups (msm_on_device): ZC_MSM_GROUPS="a,b,.." = windows per group, top group first; must add up to W.
+    p.G = 1;
+    p.gw[0] = p.W;
+    {
+        int sum = 0;
+        for (int g = 0; g < tune.msm_ngroups; g++) sum += tune.msm_groups[g];
+        if (tune.msm_ngroups >= 2 && sum == p.W) {
+            p.G = tune.msm_ngroups;
+            for (int g = 0; g < p.G; g++) p.gw[g] = tune.msm_groups[g];
+        } else if (tune.msm_ngroups == 0 && p.W >= 8 && cnt >= ((size_t)1 << 21) && cnt < ((size_t)1 << 22)) {
+            // default for config-5-sized shards (2^21 pairs: 16 windows as 9 + 4 + 3): three groups, the lowest (exposed) one the
+            // smallest.  Measured on one box, 2^21 pairs (tools/msm_groups_sweep.py): one group 3.68 ms, 13+3 3.50, 12+4 3.51,
+            // 10+6 3.74, 7+6+3 3.55, 8+5+3 3.55, 9+4+3 3.44, 6+6+4 3.50, four groups 3.8 - 4.1.  Below 2^21 and from 2^22 on
+            // the groups gain nothing (2^20: 2.39 -> 2.59 ms; 2^22: 6.27 -> 6.24; 2^24: 21.2 -> 21.6): one group.
+            p.G = 3;
+            p.gw[2] = std::max(1, (3 * p.W + 8) / 16);
+            p.gw[1] = std::max(1, (4 * p.W + 8) / 16);
+            p.gw[0] = p.W - p.gw[1] - p.gw[2];
+        }
+    }
+    // a group's launch keeps 2^17 lanes busy like the whole list (ZC_MSM_GROUP_LANES=16 / 17 / 18 / 19 at 2^21 pairs in three groups:
+    // 3.71 / 3.48 / 3.61 / 4.30 ms: shorter runs cut more buckets, and every cut is an edge for the levels behind)
+    for (int g = 0; g < p.G; g++)
+        p.gT[g] = p.G == 1 ? p.T : msm_run_length(cnt * (size_t)p.gw[g], tune, tune.msm_group_lanes ? (int)tune.msm_group_lanes : 17);
     return p;
 }
 
@@ -721,12 +775,45 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     if (cnt > 0x7FFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 31-bit point indices");
     const Tuning& tune = D.tune;
     const MsmPlan mp = msm_plan(cnt, aligned16(dP), tune);
-    const int c = mp.c, W = mp.W, seg = mp.seg, T = mp.T, TE = mp.TE;
+    const int c = mp.c, W = mp.W, seg = mp.seg, TE = mp.TE;
     const size_t m = mp.m, nb = mp.nb, nseg = mp.nseg;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
     const MsmSortPlan& plan = mp.sort;
     const bool affine = mp.affine;
-    const size_t nl0 = (m + T - 1) / T;                   // lanes (= runs) of level 0
+    // ---- window groups.  Everything behind the bucket sums -- the deeper levels of the segmented reduction, the bucket
+    // reduction, Horner's rule -- is a chain of dependent point operations on few waves: a third of a 2^21 shard during
+    // which the chip idles.  The sorted list is ordered by window, so the bucket-sum kernel is launched over the windows
+    // in GROUPS, top windows first (each launch takes its part of the list from the sort's own scan table, on the device;
+    // the launches follow one another on the caller's stream); the chain of group g -- edges, segments, folds, its stretch
+    // of Horner's rule -- runs on a side stream BESIDE the bucket sums of the groups below, with raised wave priority
+    // (zc_msm.hip.h: msm_tail_priority).  The chains of the upper groups follow one another on one side stream; only the
+    // lowest group's chain, which has the fewest buckets and the shortest stretch of Horner's rule, is exposed.  One
+    // sort, one bucket array, one workspace; G = 1 is the pipeline of rounds 2-3.
+    // (One launch for all groups with a per-group count of finished waves and a waiting kernel on the side stream was
+    // built and measured: the release fence every wave then needs writes the XCD's whole L2 back -- the launch took
+    // 2.2 - 3.3 ms instead of 1.8 -- and at 128 entries per run the launch is a single round of resident workgroups
+    // anyway, so its groups all end together.)
+    const int G = mp.G;
+    struct Group {
+        int w0 = 0, nw = 0, T = 0;
+        size_t nl0 = 0, slot0 = 0;                         // level-0 lanes (upper bound: the list part's length is known on the device only), first lane in the edge arrays
+        hipStream_t st = nullptr;
+    } grp[4];
+    size_t lanes_total = 0;
+    {
+        int top = W;
+        for (int g = 0; g < G; g++) {
+            grp[g].nw = mp.gw[g];
+            top -= mp.gw[g];
+            grp[g].w0 = top;
+            grp[g].T = mp.gT[g];
+            grp[g].nl0 = (cnt * (size_t)grp[g].nw + grp[g].T - 1) / grp[g].T;
+            grp[g].slot0 = lanes_total;
+            lanes_total += grp[g].nl0;
+            grp[g].st = g == G - 1 ? D.s() : D.grp[0];       // ONE side stream: streams of one priority share a hardware queue here anyway
+        }
+    }
+    const size_t spw = ((size_t)1 << (c - 1)) / (size_t)seg;   // segments per window (both powers of two)
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
         zc::u32* digits = cv.take<zc::u32>(m);
@@ -737,12 +824,11 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
         uint8_t* present = cv.take<uint8_t>(nb);
-        zc::u32* ekeys[2] = {cv.take<zc::u32>(2 * nl0), cv.take<zc::u32>(2 * nl0)};       // edge lists, ping-pong
-        zc::u32* erecs[2] = {cv.take<zc::u32>(2 * nl0 * zc::MSM_RAW_WORDS), cv.take<zc::u32>(2 * nl0 * zc::MSM_RAW_WORDS)};
-        u64* seg_sum = cv.take<u64>(nseg * 20);
-        u64* seg_acc = cv.take<u64>(nseg * 20);
-        u64* seg_k = cv.take<u64>(nseg * 5);
-        u64* fold_b = cv.take<u64>((nseg / 2 + 1) * 20);
+        zc::u32* ekeys[2] = {cv.take<zc::u32>(2 * lanes_total), cv.take<zc::u32>(2 * lanes_total)};       // edge lists, ping-pong
+        zc::u32* erecs[2] = {cv.take<zc::u32>(2 * lanes_total * zc::MSM_RAW_WORDS), cv.take<zc::u32>(2 * lanes_total * zc::MSM_RAW_WORDS)};
+        u64* seg_out = cv.take<u64>(nseg * 20);
+        u64* fold_b = cv.take<u64>(nseg * 20);
+        u64* grp_out = cv.take<u64>((size_t)(G + 1) * 20);  // Horner's rule after every group; the lowest group's is the result
         if (!pass) {
             int rc = ensure(&D.msm, &D.msm_bytes, cv.off);
             if (rc) return rc;
@@ -779,54 +865,87 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         }
         if (ps != D.s()) HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_join, 0));
         HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
-        // bucket sums: segmented reduction of the sorted list in runs of T, level by level
-        {
-            const zc::u32* lk = nullptr;
-            const zc::u32* lr = nullptr;
-            size_t len = m;
-            for (int level = 0;; level++) {
-                // level 0: runs [jT, (j+1)T); deeper: runs shifted by one entry, [jT+1, (j+1)T+1), run 0 one longer
-                const size_t t = level ? (size_t)TE : (size_t)T;
-                const size_t nl = level ? (len <= t + 1 ? 1 : (len - 1 + t - 1) / t) : (len + t - 1) / t;
-                zc::u32* nk = ekeys[level & 1];
-                zc::u32* nr = erecs[level & 1];
-                if (level == 0)
-                    hipLaunchKernelGGL(affine ? zc::k_msm_runs_affine : zc::k_msm_runs, dim3((unsigned)((nl + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), 0, D.s(), sorted, (const zc::u32*)cached,
-                                       (zc::u32)len, (zc::u32)t, (zc::u32)nb, buckets, present, nk, nr);
-                else
-                    hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, D.s(), lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
-                                       buckets, present, nk, nr);
-                if (nl <= 1) break;                        // one lane saw the whole list: nothing is left open
-                if (level > 40) return fail(ZC_ERR_HIP, "zc_msm: segmented reduction did not converge");
-                lk = nk;
-                lr = nr;
-                len = 2 * nl;
+        // where window w's part of the sorted list starts: the last pass's scanned table at (window w, bin 0, column 0); the row
+        // behind the last window is the zero digits' = the end of the buckets (zc_sort.hip.h: msm_sort_slot)
+        const zc::msm_sort_pass& lastp = plan.pass[plan.passes - 1];
+        const zc::u32* last_table = sort_table + (size_t)((plan.passes - 1) & 1) * plan.table_words;
+        auto window_start = [&](int w) { return last_table + ((size_t)w << lastp.bits) * lastp.ncols; };
+        for (int g = 0; g < G; g++) {
+            Group& gr = grp[g];
+            const size_t b0 = (size_t)gr.w0 << (c - 1);                  // the group's first bucket
+            const size_t nsegg = (size_t)gr.nw * spw;
+            // A launch that runs beside the chain of the group above it leaves that chain room: its workgroups are padded with
+            // dynamic LDS so that only `wgs` of them fit a CU (three: one wave slot per SIMD, 200 VGPRs and 39 KB of LDS stay free;
+            // a chain kernel that finds every slot taken waits for a bucket-sum workgroup to retire).
+            size_t pad = 0;
+            if (g > 0) {
+                const long wgs = tune.msm_group_wgs >= 0 ? tune.msm_group_wgs : 3;
+                const size_t own = (affine ? 6 : 8) * 16 * (size_t)zc::MSM_RUN_BLOCK;       // the kernel's static staging area
+                if (wgs > 0 && (size_t)(wgs + 1) * own <= 163840) {
+                    const size_t per = 163840 / (size_t)(wgs + 1) + 512;                     // wgs + 1 of these do not fit 160 KB
+                    pad = per > own ? std::min<size_t>(per - own, 65536 - own) : 0;
+                }
             }
+            hipLaunchKernelGGL(affine ? zc::k_msm_runs_affine : zc::k_msm_runs, dim3((unsigned)((gr.nl0 + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), pad,
+                               D.s(), sorted, (const zc::u32*)cached, (zc::u32)m, (zc::u32)gr.T, (zc::u32)nb, buckets, present, ekeys[0], erecs[0],
+                               G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0), G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0 + gr.nw), (zc::u32)gr.nl0,
+                               (zc::u32)gr.slot0);
+            hipStream_t st = tune.msm_tail_side == 0 ? D.s() : gr.st;
+            if (st != D.s()) {
+                HIP_TRY(hipEventRecord(D.ev_grp_go[g], D.s()));
+                HIP_TRY(hipStreamWaitEvent(st, D.ev_grp_go[g], 0));
+            }
+            // deeper levels of the segmented reduction: the edge list of the level above, level by level, in short runs (a bucket
+            // cut once closes at level 1: nearly every edge of a uniform batch; the levels behind it find sentinel keys only and
+            // take 5 us each.  Runs of 64 there -- 5 launches instead of 9 -- were measured: a lane then walks 64 sentinel keys
+            // one dependent load after the other, 340 us per level instead of 5).
+            {
+                const zc::u32* lk = ekeys[0] + 2 * gr.slot0;
+                const zc::u32* lr = erecs[0] + 2 * gr.slot0 * zc::MSM_RAW_WORDS;
+                size_t len = 2 * gr.nl0;
+                for (int level = 1; gr.nl0 > 1; level++) {
+                    // runs shifted by one entry, [jT+1, (j+1)T+1), run 0 one longer
+                    const size_t t = (size_t)TE;
+                    const size_t nl = len <= t + 1 ? 1 : (len - 1 + t - 1) / t;
+                    zc::u32* nk = ekeys[level & 1] + 2 * gr.slot0;
+                    zc::u32* nr = erecs[level & 1] + 2 * gr.slot0 * zc::MSM_RAW_WORDS;
+                    hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, st, lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
+                                       buckets, present, nk, nr);
+                    if (nl <= 1) break;                    // one lane saw the whole list: nothing is left open
+                    if (level > 40) return fail(ZC_ERR_HIP, "zc_msm: segmented reduction did not converge");
+                    lk = nk;
+                    lr = nr;
+                    len = 2 * nl;
+                }
+            }
+            // bucket reduction: one lane per segment -> sum_j (first' + j + 1) B_(first + j), the product by first' included
+            u64* cur = seg_out + 20 * (size_t)gr.w0 * spw;
+            u64* nxt = fold_b + 20 * (size_t)gr.w0 * spw;
+            // few segments (the lowest group, small shards): four lanes per segment, three multiplication latencies per addition
+            const size_t quad_max = tune.msm_seg_quad >= 0 ? (size_t)tune.msm_seg_quad : QUAD_LAUNCH_ELEMS;
+            if (nsegg <= quad_max)
+                hipLaunchKernelGGL(zc::k_msm_segments_quad, dim3((unsigned)((nsegg + 63) / 64)), dim3(zc::ZC_BLOCK), 0, st, (const zc::u32*)(buckets + b0 * zc::MSM_RAW_WORDS),
+                                   (const uint8_t*)(present + b0), cur, nsegg, c, seg);
+            else
+                hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nsegg)), dim3(zc::ZC_BLOCK), 0, st, (const zc::u32*)(buckets + b0 * zc::MSM_RAW_WORDS),
+                                   (const uint8_t*)(present + b0), cur, nsegg, c, seg);
+            // fold every window's segment sums (a power of two per window) to one point per window:
+            // one workgroup per group of up to 512 points, two launches at most
+            size_t left = nsegg;
+            while (left > (size_t)gr.nw) {
+                const size_t fg = std::min<size_t>(512, left / (size_t)gr.nw);
+                hipLaunchKernelGGL(zc::k_msm_fold_groups, dim3((unsigned)(left / fg)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)cur, nxt, (zc::u32)fg);
+                left /= fg;
+                std::swap(cur, nxt);
+            }
+            // Horner's rule, top window first across the groups: this group continues from the result of the group above it
+            // (same stream, or -- the lowest group -- behind that stream's event)
+            if (g == G - 1 && G > 1 && tune.msm_tail_side != 0) HIP_TRY(hipStreamWaitEvent(st, D.ev_grp_done[G - 2], 0));
+            hipLaunchKernelGGL(zc::k_msm_window_combine, dim3(1), dim3(64), 0, st, (const u64*)cur, grp_out + 20 * (size_t)g, gr.nw, c,
+                               g > 0 ? (const u64*)(grp_out + 20 * (size_t)(g - 1)) : (const u64*)nullptr);
+            if (st != D.s()) HIP_TRY(hipEventRecord(D.ev_grp_done[g], st));
         }
-        hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)buckets, (const uint8_t*)present, seg_sum, seg_acc, seg_k, nseg, c, seg);
-        // seg_acc <- (first mod 2^(c-1)) * seg_acc ; seg_sum <- seg_sum + seg_acc
-        // few segments (small MSMs): four lanes per element, three multiplication latencies per step instead of nine
-        // (2^16 pairs: 1.11 -> 1.065 ms; with 2^16 segments -- 2^20 pairs and up -- the quad form is 3 % slower overall)
-        if (nseg <= QUAD_LAUNCH_ELEMS)
-            hipLaunchKernelGGL(zc::k_ed_scalar_mul_quad, dim3((unsigned)((nseg + 63) / 64)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, seg_acc, nseg);
-        else
-            hipLaunchKernelGGL(strict_kernel_for(nseg), dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_acc, (const u64*)seg_k, (size_t)5,
-                               seg_acc, (const zc::u32*)nullptr, nseg);
-        hipLaunchKernelGGL(zc::k_ed_add, dim3(grid_for(nseg)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)seg_sum, (const u64*)seg_acc, seg_sum, nseg);
-        // fold every window's nseg/W segment sums (a power of two per window) to one point per window:
-        // one workgroup per group of up to 512 points, two launches at most
-        size_t left = nseg;
-        u64* cur = seg_sum;
-        u64* nxt = fold_b;
-        while (left > (size_t)W) {
-            const size_t g = std::min<size_t>(512, left / (size_t)W);
-            hipLaunchKernelGGL(zc::k_msm_fold_groups, dim3((unsigned)(left / g)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)cur, nxt, (zc::u32)g);
-            left /= g;
-            std::swap(cur, nxt);
-        }
-        // sum_w 2^(c w) S_w
-        hipLaunchKernelGGL(zc::k_msm_window_combine, dim3(1), dim3(64), 0, D.s(), (const u64*)cur, nxt, W, c);
-        *result = nxt;
+        *result = grp_out + 20 * (size_t)(G - 1);
         HIP_TRY(hipGetLastError());
     }
     return ZC_OK;
@@ -959,6 +1078,13 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming);
+        for (int g = 0; g < 3 && e == hipSuccess; g++) {
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+            e = hipStreamCreateWithPriority(&ds.grp[g], hipStreamNonBlocking, tune.msm_tail_prio == 0 ? 0 : hi_p);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_grp_go[g], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_grp_done[g], hipEventDisableTiming);
+        }
         if (e != hipSuccess) {
             delete ctx;
             return fail(ZC_ERR_HIP, "stream creation", e);
@@ -982,6 +1108,11 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.ev_fork) (void)hipEventDestroy(ds.ev_fork);
         if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
         if (ds.aux) (void)hipStreamDestroy(ds.aux);
+        for (int g = 0; g < 3; g++) {
+            if (ds.grp[g]) (void)hipStreamSynchronize(ds.grp[g]), (void)hipStreamDestroy(ds.grp[g]);
+            if (ds.ev_grp_go[g]) (void)hipEventDestroy(ds.ev_grp_go[g]);
+            if (ds.ev_grp_done[g]) (void)hipEventDestroy(ds.ev_grp_done[g]);
+        }
         for (int a = 0; a < MAX_ARGS; a++)
             if (ds.scratch[a]) (void)hipFree(ds.scratch[a]);
         for (int a = 0; a < 2; a++)
@@ -1623,13 +1754,13 @@ int zc_test_odd_table(zc_ctx* ctx, uint64_t* out_dev_points)
 // work.  A measurement aid: a roofline record counts the useful multiplications from c, W and the addition formula.
 // out8: [0] window bits c (0: below the bucket threshold, n scalar multiplications + folds), [1] windows W,
 // [2] 1 = affine 96-byte records / 7-multiplication additions, 0 = projective 128-byte / 8, [3] bytes per gathered
-// record, [4] run length T of the bucket-sum kernel, [5] buckets per reduction segment, [6] sort passes, [7] 0.
+// record, [4] run length T of the bucket-sum kernel, [5] buckets per reduction segment, [6] sort passes, [7] window groups.
 int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out8)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
     REQUIRE(out8);
     const MsmPlan p = msm_plan(n, points_aligned16 != 0, ctx->devs[0].tune);
-    const int32_t v[8] = {p.c, p.W, p.affine ? 1 : 0, p.buckets ? (p.affine ? 96 : 128) : 0, p.T, p.seg, p.sort.passes, 0};
+    const int32_t v[8] = {p.c, p.W, p.affine ? 1 : 0, p.buckets ? (p.affine ? 96 : 128) : 0, p.T, p.seg, p.sort.passes, p.buckets ? p.G : 0};
     memcpy(out8, v, sizeof v);
     return ZC_OK;
 }

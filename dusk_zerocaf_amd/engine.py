@@ -428,7 +428,7 @@ class Engine:
         v = (C.c_int32 * 8)()
         self._call("zc_msm_plan", int(n), 1 if points_aligned16 else 0, v)
         return {"window_bits": v[0], "windows": v[1], "affine": bool(v[2]), "record_bytes": v[3], "run": v[4],
-                "segment_buckets": v[5], "sort_passes": v[6]}
+                "segment_buckets": v[5], "sort_passes": v[6], "window_groups": v[7]}
 
     def ris_mul_base_compress(self, k):
         k, pk, n = self._prep(k, 5, np.uint64)

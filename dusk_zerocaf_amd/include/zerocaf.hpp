@@ -623,7 +623,7 @@ inline std::vector<EdwardsPoint> window_naf_mul_batch(const std::vector<Scalar>&
     for (size_t i = 0; i < ks.size(); i++) out[i] = EdwardsPoint::unflat(&o[20 * i]);
     return out;
 }
-// the bucket method's plan for a shard of n pairs: {c, W, affine, record bytes, run, segment, sort passes, 0}
+// the bucket method's plan for a shard of n pairs: {c, W, affine, record bytes, run, segment, sort passes, window groups}
 inline std::array<int32_t, 8> msm_plan(size_t n, bool points_aligned16 = true)
 {
     std::array<int32_t, 8> v{};

@@ -249,7 +249,7 @@ int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t 
  *                       context -- out8 = {window bits c (0: below the bucket threshold, n scalar multiplications +
  *                       folds), windows W, 1 = affine 96-byte records and 7-multiplication additions / 0 = projective
  *                       128-byte records and 8, bytes per gathered record, run length of the bucket-sum kernel,
- *                       buckets per reduction segment, sort passes, 0}.  What a roofline record counts its useful
+ *                       buckets per reduction segment, sort passes, window groups}.  What a roofline record counts its useful
  *                       work from (bench.py); points_aligned16: whether the point array is 16-byte aligned.           */
 int zc_msm_partial(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
                    uint64_t *out_dev_point);

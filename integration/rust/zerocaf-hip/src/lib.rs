@@ -572,7 +572,7 @@ impl HipBackend {
     }
 
     /// The bucket method's plan for a shard of `n` pairs on this context (a query, no device work):
-    /// `[c, W, affine, record bytes, run length, buckets per segment, sort passes, 0]`.
+    /// `[c, W, affine, record bytes, run length, buckets per segment, sort passes, window groups]`.
     pub fn msm_plan(&self, n: usize, points_aligned16: bool) -> Result<[i32; 8]> {
         let mut v = [0i32; 8];
         check(unsafe { ffi::zc_msm_plan(self.ctx, n, points_aligned16 as i32, v.as_mut_ptr()) })?;

@@ -45,6 +45,49 @@ def test_single_rank_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_single_core"] > 0
     assert d["distinct_devices"] == 1 and len(d["devices"]) == 1 and d["devices"][0]["pci"]
     assert d["config"]["units_per_gpu_per_step"] == 1 << 20 and abs(d["value"] - (1 << 20) / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    assert d["config"]["workload"].startswith("2^20 ") and r["schema"] == "useful-work/2" and "-march=native" in c["sample"]
+    # the default single-GPU line carries the other BASELINE configs (and the reference's ECDH macro-benchmark) as `secondary`:
+    # driver-box numbers for every config, each with its own roofline record and oracle spot check, outside the headline's timing
+    sec = {x["name"]: x for x in d["secondary"]}
+    assert list(sec) == ["fe_mul", "fe_invert", "ristretto", "msm", "ecdh"]
+    assert [sec[k]["units"] for k in sec] == [1 << 24, 1 << 20, 1 << 22, 1 << 21, 1 << 20]
+    for k, x in sec.items():
+        lg = x["units"].bit_length() - 1
+        assert x["parity_spot_check"] is True and x["workload"].startswith("2^%d" % lg), k
+        assert x["ms_per_step"] > 0 and abs(x["value"] - x["units"] / (x["ms_per_step"] * 1e-3)) < 0.01 * x["value"], k
+        assert {"bound", "frac", "achieved", "peak", "kernel_avg_ms"} <= set(x["roofline"]) and 0 < x["roofline"]["frac"] < 1.2, k
+    assert sec["fe_mul"]["roofline"]["bound"] == "hbm" and sec["fe_mul"]["roofline"]["cache_resident"] is False
+    assert sec["msm"]["msm_result_is_fold_of_shard_partials"] is True and sec["msm"]["rccl_ranks"] == 1
+    assert sec["msm"]["roofline"]["useful"]["plan"]["window_groups"] == 3 and sec["msm"]["roofline"]["useful"]["multiplications_per_bucket_addition"] == 7
+    assert sec["ecdh"]["roofline"]["bound"] == "valu_int_mul"
+
+
+@pytest.mark.gpu
+def test_workload_string_names_the_size_it_ran_at():
+    """`config.workload` is derived from --units (a record of a 2^18-unit run must not say 2^20); other sizes carry no `secondary`."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--units", str(1 << 18), "--cpu-sample", "2048"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _one_json_line(out.stdout)
+    assert d["config"]["workload"].startswith("2^18 ") and d["config"]["units_per_gpu_per_step"] == 1 << 18 and "secondary" not in d
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--units", "300000", "--workload", "fe_mul", "--cpu-sample", "4096"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert _one_json_line(out.stdout)["config"]["workload"].startswith("300000 ")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["wire", "reference"])
+def test_ecdh_workload(variant):
+    """The reference's macro-benchmark (benchmarks/dusk_benchmarks.rs:544-620): two key generations and two shared secrets per
+    unit.  `wire`: 32-byte Ristretto encodings, equal to compress() of the oracle's ecdh_double_add key pairs and secrets;
+    `reference`: the four double_and_add calls literally, limb-exact.  S == S' on every element either way (bench.py aborts otherwise)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ecdh", "--ecdh", variant, "--units", str(1 << 16), "--steps", "2",
+                          "--warmup", "1", "--cpu-sample", "1024"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _one_json_line(out.stdout)
+    assert d["parity_spot_check"] is True and d["unit"] == "exchanges/s" and d["config"]["workload"].startswith("2^16 ECDH")
+    assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.gpu

@@ -953,7 +953,7 @@ def test_window_naf_mul_in_one_launch(eng, oracle, kats):
         vals = [sum(int(d) << i for i, d in enumerate(row)) % pm.L for row in naf]
         kv = [sum(int(K[i, j]) << (52 * j) for j in range(5)) for i in range(n)]
         exact = np.array([a == b for a, b in zip(vals, kv)])
-        assert exact[:5 + 125].all()                               # the digits of small / ordinary scalars represent them
+        assert exact[:2].all() and exact[5:5 + 125].all()          # the digits of small / ordinary scalars represent them (L - 1, L - 2 wrap)
         assert oracle.ed_eq(got[exact], want[exact]).all(), w
         assert eq(eng.ed_compress(got[exact])[0], eng.ed_compress(comb[exact])[0]), w
         if (~exact).any():                                         # near L the reference's digits stand for another integer: follow them
@@ -1150,11 +1150,14 @@ def test_msm_skewed_digit_distributions(eng, oracle):
 @pytest.mark.parametrize("knobs", [
     dict(ZC_MSM_AFFINE=0), dict(ZC_MSM_AFFINE=0, ZC_MSM_FORK=1), dict(ZC_MSM_FORK=0), dict(ZC_MSM_FORK=1),
     dict(ZC_MSM_RUN_EDGES=4), dict(ZC_MSM_RUN_EDGES=32, ZC_MSM_RUN=16), dict(ZC_MSM_AFFINE_CHUNK=1), dict(ZC_MSM_AFFINE_CHUNK=5, ZC_MSM_SEG=4),
-    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12), dict(ZC_MSM_GROUPS="17,4"), dict(ZC_MSM_GROUPS="12,5,4", ZC_MSM_SEG_QUAD=0),
+    dict(ZC_MSM_GROUPS="6,5,5,5", ZC_MSM_SEG_QUAD=1 << 20), dict(ZC_MSM_GROUPS="11,6,4", ZC_MSM_TAIL_SIDE=0, ZC_MSM_GROUP_WGS=0),
+    dict(ZC_MSM_GROUPS="9,8,4", ZC_MSM_GROUP_LANES=19, ZC_MSM_GROUP_WGS=2, ZC_MSM_TAIL_PRIO=0), dict(ZC_MSM_GROUPS="20,1", ZC_MSM_AFFINE=0)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
     """Every MSM path a ZC_* knob can select in the shipped library (projective 128-byte records at a size where the
     default is affine, the normalisation forked onto the second stream or kept in line, other edge-run lengths, other
-    normalisation chunkings and segment lengths), at 2^17 + 333 pairs (where the affine path and the persistent
+    normalisation chunkings and segment lengths, the windows in two / three / four groups with their chains on the side
+    stream or in line, four lanes per segment or one), at 2^17 + 333 pairs (where the affine path and the persistent
     structures are live), against the ORACLE's sum of the reference's Mul<Scalar> + Add."""
     n = (1 << 17) + 333
     P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 410, bits=249))
@@ -1164,8 +1167,12 @@ def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
     want = oracle.msm_naive_mt(P, K)
     wenc = oracle.ed_compress(want)[0]
     with V.tuned(**knobs) as te:
+        if "ZC_MSM_GROUPS" in knobs:                              # the split is really in force (it must add up to the windows)
+            assert te.msm_plan(n)["window_groups"] == len(knobs["ZC_MSM_GROUPS"].split(",")) and te.msm_plan(n)["windows"] == 21
         got = te.msm(P, K)
         assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), knobs
+        for _ in range(2):                                        # and again: the side stream's events and the workspace are reused
+            assert eq(te.msm(P, K), got), knobs
         small = te.msm(P[:5000], K[:5000])                         # and a shard below the affine threshold under the same knobs
     wsmall = oracle.msm_naive_mt(P[:5000], K[:5000])
     assert oracle.ed_eq(small, wsmall)[0] == 1, knobs
@@ -1233,11 +1240,18 @@ def test_msm_config5_shard_2_21_vs_oracle(eng, oracle):
     n = 1 << 21
     P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 89, bits=249))
     K = V.rand_scalars_np(n, V.SEED + 90, bits=249)
+    assert eng.msm_plan(n)["window_groups"] == 3                   # the shard's default: its windows in three groups, chains on the side stream
     got = eng.msm(P, K)
     want = oracle.msm_naive_mt(P, K)
     assert oracle.ed_eq(got, want)[0] == 1
     assert eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0])
     assert eq(oracle.ris_compress(got), oracle.ris_compress(want))
+    with V.tuned(ZC_MSM_GROUPS="1") as te:                         # one group (the pipeline of rounds 2-3): the same point
+        assert te.msm_plan(n)["window_groups"] == 1 and oracle.ed_eq(te.msm(P, K), want)[0] == 1
+    K2 = V.rand_scalars_np(n, V.SEED + 96, bits=252)               # raw 252-bit patterns, equal stretches, zeros: every group has edges to close
+    K2[n // 3:n // 3 + 50000] = K2[7]
+    K2[::1001] = 0
+    assert oracle.ed_eq(eng.msm(P, K2), oracle.msm_naive_mt(P, K2))[0] == 1
 
 
 @pytest.fixture(scope="module")
