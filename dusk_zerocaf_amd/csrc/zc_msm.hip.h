@@ -123,7 +123,9 @@ ZC_DI void coop_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, i
 {
     for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) dst[v] = src[v];
 }
-ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c)
+// `rec_words`: the record stride in 32-bit words -- 24 (records packed, 96 bytes: three of four straddle two 128-byte lines)
+// or 32 (one record per 128-byte line, a quarter of the array unused).
+ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c, u32 rec_words)
 {
     __shared__ __attribute__((aligned(16))) u64 sp[ZC_BLOCK * 20];          // 256 point records in, 256 affine records out
     __shared__ __attribute__((aligned(16))) u32 spre[ZC_BLOCK * 9];         // 256 prefix products
@@ -154,7 +156,7 @@ ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, i
         __syncthreads();
         // the step's prefix products wait in the first 9 KB of the 24 KB the step's records will occupy (whole 16-byte
         // vectors: the tail of a partial block may run a few words into the next lane-less slots of the same region)
-        coop_copy16(reinterpret_cast<uint4*>(recs + MSM_AFF_WORDS * base), reinterpret_cast<const uint4*>(spre), (cnt * 9 + 3) / 4);
+        coop_copy16(reinterpret_cast<uint4*>(recs + (size_t)rec_words * base), reinterpret_cast<const uint4*>(spre), (cnt * 9 + 3) / 4);
     }
     // one inversion per lane (the lanes of a wave run it in lock step: it is shared by the lane's own points, not across lanes);
     // a workgroup whose points all have Z = 1 needs none
@@ -172,7 +174,7 @@ ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, i
         const int cnt = (int)(n - base < (size_t)ZC_BLOCK ? n - base : (size_t)ZC_BLOCK);
         __syncthreads();
         coop_load40<false>(sp, points + 20 * base, cnt * 4);
-        if (!skip) coop_copy16(reinterpret_cast<uint4*>(spre), reinterpret_cast<const uint4*>(recs + MSM_AFF_WORDS * base), (cnt * 9 + 3) / 4);
+        if (!skip) coop_copy16(reinterpret_cast<uint4*>(spre), reinterpret_cast<const uint4*>(recs + (size_t)rec_words * base), (cnt * 9 + 3) / 4);
         __syncthreads();
         fe ymx, ypx, t2d;
         if (t < cnt) {
@@ -206,7 +208,12 @@ ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, i
             pack256(o + 16, t2d);
         }
         __syncthreads();
-        coop_copy16(reinterpret_cast<uint4*>(recs + MSM_AFF_WORDS * base), reinterpret_cast<const uint4*>(sp), cnt * 6);
+        {
+            uint4* dst = reinterpret_cast<uint4*>(recs + (size_t)rec_words * base);
+            const uint4* src = reinterpret_cast<const uint4*>(sp);
+            const u32 rv = rec_words / 4;                       // 16-byte pieces per record slot: 6 (packed) or 8
+            for (int v = threadIdx.x; v < cnt * 6; v += ZC_BLOCK) dst[(size_t)(v / 6) * rv + (v % 6)] = src[v];
+        }
     }
 }
 // Bucket sums are kept in the kernels' own number system between k_msm_runs and k_msm_segments:
@@ -310,7 +317,7 @@ ZC_DI void msm_tail_priority() { __builtin_amdgcn_s_setprio(3); }
 // lie in another group (another window: another key).  `sj`: the lane's number in the edge arrays (groups share them).
 template <bool AFFINE>
 ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict__ recs, u32 len, u32 T, u32 nbuckets,
-                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 j, u32 sj)
+                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 j, u32 sj, u32 rec_words)
 {
     constexpr int PIECES = AFFINE ? 6 : 8;                     // 16-byte pieces of a cached record
     __shared__ uint4 stage[PIECES * MSM_RUN_BLOCK];
@@ -332,9 +339,9 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     const u32 next_key = hi < len ? pairs[hi].x : none;
     auto fetch = [&](u32 v) {
 #ifdef ZC_MSM_PROBE_NOGATHER   // timing probe only (wrong sums): every gather hits one of 256 cache-resident records
-        const uint4* src = reinterpret_cast<const uint4*>(recs + 4 * PIECES * (size_t)(v & 0xFFu));
+        const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)rec_words * (size_t)(v & 0xFFu));
 #else
-        const uint4* src = reinterpret_cast<const uint4*>(recs + 4 * PIECES * (size_t)(v & 0x7FFFFFFFu));
+        const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)rec_words * (size_t)(v & 0x7FFFFFFFu));
 #endif
 #pragma unroll
         for (int q = 0; q < PIECES; q++)
@@ -395,17 +402,17 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
 }
 extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0)
+                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0, u32 rec_words)
 {
     const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
-    if (j < nlanes) msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j);
+    if (j < nlanes) msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j, rec_words);
 }
 extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs_affine(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0)
+                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0, u32 rec_words)
 {
     const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
-    if (j < nlanes) msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j);
+    if (j < nlanes) msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j, rec_words);
 }
 
 // Levels >= 1: the edge list of the level above (raw 144-byte records in list order, sentinel keys in

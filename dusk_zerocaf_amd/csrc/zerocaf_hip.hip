@@ -71,6 +71,7 @@ struct Tuning {
     int msm_tail_prio = -1;          // ZC_MSM_TAIL_PRIO=0/1: the groups' tails on high-priority streams (default 1)
     long msm_seg_quad = -1;          // ZC_MSM_SEG_QUAD=s: four lanes per segment in launches of at most s segments (0: never)
     long msm_group_lanes = 0;        // ZC_MSM_GROUP_LANES=l: lanes a window group's bucket-sum launch keeps busy (log2, 15..22)
+    int msm_rec_stride = 0;          // ZC_MSM_REC_STRIDE=96/128: stride of the affine records (128: one record per cache line)
     int msm_tail_side = -1;          // ZC_MSM_TAIL_SIDE=0: the groups' chains on the caller's stream, one after the other (A/B: no overlap)
     long msm_group_wgs = -1;         // ZC_MSM_GROUP_WGS=k: workgroups per CU of the bucket-sum launches that run beside a tail (0: no limit)
 #ifdef ZC_TEST_HOOKS
@@ -123,6 +124,10 @@ Tuning tuning_from_env()
     t.msm_group_lanes = env_long("ZC_MSM_GROUP_LANES", 15, 22, 0);
     t.msm_group_wgs = env_long("ZC_MSM_GROUP_WGS", 0, 8, -1);
     t.msm_tail_side = (int)env_long("ZC_MSM_TAIL_SIDE", 0, 1, -1);
+    {
+        const long v = env_long("ZC_MSM_REC_STRIDE", 96, 128, 0);
+        if (v == 96 || v == 128) t.msm_rec_stride = (int)v;
+    }
 #ifdef ZC_TEST_HOOKS
     t.test_ring_poison = getenv("ZC_TEST_RING_POISON") != nullptr;
     t.test_ring_spins = (unsigned)env_long("ZC_TEST_RING_SPINS", 1, 30, 0);
@@ -699,6 +704,7 @@ struct MsmPlan {
     int T = 0, TE = 0;             // run lengths of the segmented reduction: level 0, deeper levels
     int seg = 0;                   // buckets per reduction segment
     size_t m = 0, nb = 0, nseg = 0;   // list entries (n W), buckets, segments
+    int rec_bytes = 128;           // stride of the cached records (affine: 96 packed or 128 = one per cache line; projective: 128)
     int G = 1;                     // window groups, top windows first: gw[g] windows, run length gT[g]
     int gw[4] = {0, 0, 0, 0}, gT[4] = {0, 0, 0, 0};
     MsmSortPlan sort;
@@ -726,6 +732,7 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     p.nseg = p.nb / (size_t)p.seg;
     p.sort = msm_sort_plan(cnt, p.c, p.W, tune);
     p.affine = msm_affine(cnt, tune) && points_aligned16;  // the normalisation moves the point records with 16-byte loads
+    p.rec_bytes = p.affine ? (tune.msm_rec_stride ? tune.msm_rec_stride : 96) : 128;
     p.T = msm_run_length(p.m, tune);
     p.TE = 8;                                             // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
     if (tune.msm_run_edges) p.TE = tune.msm_run_edges & ~1;
@@ -814,6 +821,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         }
     }
     const size_t spw = ((size_t)1 << (c - 1)) / (size_t)seg;   // segments per window (both powers of two)
+    const zc::u32 rec_words = affine ? (zc::u32)(mp.rec_bytes / 4) : 32u;
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
         zc::u32* digits = cv.take<zc::u32>(m);
@@ -852,7 +860,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             int ac = (int)std::min<size_t>(16, std::max<size_t>(1, cnt >> 18));
             if (tune.msm_affine_chunk) ac = tune.msm_affine_chunk;
             const size_t lanes = (cnt + ac - 1) / ac;            // lane g owns points g, g + stride, ...: stride = the launch's lanes
-            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt, ac);
+            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt, ac, rec_words);
         } else {
             hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt);
         }
@@ -889,7 +897,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             hipLaunchKernelGGL(affine ? zc::k_msm_runs_affine : zc::k_msm_runs, dim3((unsigned)((gr.nl0 + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), pad,
                                D.s(), sorted, (const zc::u32*)cached, (zc::u32)m, (zc::u32)gr.T, (zc::u32)nb, buckets, present, ekeys[0], erecs[0],
                                G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0), G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0 + gr.nw), (zc::u32)gr.nl0,
-                               (zc::u32)gr.slot0);
+                               (zc::u32)gr.slot0, rec_words);
             hipStream_t st = tune.msm_tail_side == 0 ? D.s() : gr.st;
             if (st != D.s()) {
                 HIP_TRY(hipEventRecord(D.ev_grp_go[g], D.s()));
@@ -1760,7 +1768,7 @@ int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out8)
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
     REQUIRE(out8);
     const MsmPlan p = msm_plan(n, points_aligned16 != 0, ctx->devs[0].tune);
-    const int32_t v[8] = {p.c, p.W, p.affine ? 1 : 0, p.buckets ? (p.affine ? 96 : 128) : 0, p.T, p.seg, p.sort.passes, p.buckets ? p.G : 0};
+    const int32_t v[8] = {p.c, p.W, p.affine ? 1 : 0, p.buckets ? p.rec_bytes : 0, p.T, p.seg, p.sort.passes, p.buckets ? p.G : 0};
     memcpy(out8, v, sizeof v);
     return ZC_OK;
 }

@@ -81,6 +81,14 @@ def test_release_library_carries_no_test_hooks_and_reads_its_knobs_once(lib):
     assert "env_long(" in body and outside.count("env_long(") == 1                      # its definition only
 
 
+def test_documents_quote_the_real_entry_point_count():
+    """INTEGRATION.md and README.md name the number of entry points; it must be the header's."""
+    n = len(declared_symbols())
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "**all %d** entry points" % n in integ and "\n%d entry points (" % n in integ
+    assert "%d entry points" % n in open(os.path.join(ROOT, "README.md")).read()
+
+
 def test_rust_shim_binds_the_whole_abi():
     """integration/rust/zerocaf-hip (source only: no Rust toolchain here) declares every entry
     point of the header -- ffi.rs is generated from it -- and its safe layer calls each one."""

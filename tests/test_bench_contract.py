@@ -120,4 +120,6 @@ def test_msm_line_reports_the_library_communicator():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _one_json_line(out.stdout)
     assert d["rccl_ranks"] == 1 and d["msm_result_is_fold_of_shard_partials"] is True and d["parity_spot_check"] is True
-    assert d["roofline"]["useful"]["multiplications_per_bucket_addition"] == 7 and 0 < d["roofline"]["frac"] < 1
+    # 2^16 pairs lie below the affine threshold: projective 128-byte records, 8 multiplications per bucket addition (the library's own plan)
+    u = d["roofline"]["useful"]
+    assert u["multiplications_per_bucket_addition"] == 8 and u["plan"]["affine"] is False and u["plan"]["record_bytes"] == 128 and 0 < d["roofline"]["frac"] < 1
