@@ -732,7 +732,10 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     p.nseg = p.nb / (size_t)p.seg;
     p.sort = msm_sort_plan(cnt, p.c, p.W, tune);
     p.affine = msm_affine(cnt, tune) && points_aligned16;  // the normalisation moves the point records with 16-byte loads
-    p.rec_bytes = p.affine ? (tune.msm_rec_stride ? tune.msm_rec_stride : 96) : 128;
+    // affine records: 96 bytes of payload at a 128-byte stride -- one record per cache line.  Packed (96-byte stride) three records
+    // of four straddle two lines: measured (rocprofv3 TCC_EA0_RDREQ of k_msm_runs_affine, profiles/r04_msm_record_stride.md)
+    // 34.6 -> 25.1 read requests per pair at 2^21 pairs, 34.3 -> 27.7 at 2^24; 2^21: 3.50 -> 3.50 ms, 2^22: 6.30 -> 6.13, 2^24: 21.18 -> 20.22.
+    p.rec_bytes = p.affine ? (tune.msm_rec_stride ? tune.msm_rec_stride : 128) : 128;
     p.T = msm_run_length(p.m, tune);
     p.TE = 8;                                             // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
     if (tune.msm_run_edges) p.TE = tune.msm_run_edges & ~1;

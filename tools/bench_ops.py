@@ -38,7 +38,7 @@ def main():
                 edc, _ = eng.ed_compress(pts)
             bytes_per = {"fe_add": 120, "fe_sub": 120, "fe_mul": 120, "fe_square": 80, "fe_neg": 80, "fe_invert": 80, "fe_div": 120,
                          "sc_mul": 120, "ed_add": 480, "ed_double": 320, "ed_compress": 192, "ed_decompress": 192,
-                         "ris_compress": 192, "ris_decompress": 192, "ed_to_affine": 240, "fe_sqrt_ratio_i": 120, "fe_legendre": 41, "ed_neg": 320, "ed_eq": 321, "ris_eq": 321, "ed_is_valid": 161, "ed_mul_base": 200, "ris_mul_base_compress": 72}[op]
+                         "ris_compress": 192, "ris_decompress": 192, "ed_to_affine": 240, "fe_sqrt_ratio_i": 120, "fe_legendre": 41, "ed_neg": 320, "ed_eq": 321, "ris_eq": 321, "ed_is_valid": 161, "ed_mul_base": 200, "ris_mul_base_compress": 72, "ed_mul_base_wnaf5": 200}[op]
             fn = {"fe_add": lambda: eng.fe_add(a, b), "fe_sub": lambda: eng.fe_sub(a, b), "fe_mul": lambda: eng.fe_mul(a, b),
                   "fe_square": lambda: eng.fe_square(a), "fe_neg": lambda: eng.fe_neg(a), "fe_invert": lambda: eng.fe_invert(a), "fe_div": lambda: eng.fe_div(a, b),
                   "sc_mul": lambda: eng.sc_mul(a, b), "fe_sqrt_ratio_i": lambda: eng.fe_sqrt_ratio_i(a, b), "fe_legendre": lambda: eng.fe_legendre_symbol(a),
@@ -48,7 +48,8 @@ def main():
                   "ed_to_affine": lambda: eng.ed_to_affine(pts),
                   "ed_neg": lambda: eng.ed_neg(pts), "ed_eq": lambda: eng.ed_eq(pts, pts2), "ris_eq": lambda: eng.ris_eq(pts, pts2),
                   "ed_is_valid": lambda: eng.ed_is_valid(pts),
-                  "ed_mul_base": lambda: eng.ed_mul_base(a), "ris_mul_base_compress": lambda: eng.ris_mul_base_compress(a)}[op]
+                  "ed_mul_base": lambda: eng.ed_mul_base(a), "ris_mul_base_compress": lambda: eng.ris_mul_base_compress(a),
+                  "ed_mul_base_wnaf5": lambda: eng.ed_mul_base_wnaf(a, 5)}[op]
             fn()
             fn()
             torch.cuda.synchronize()

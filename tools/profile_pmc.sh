@@ -4,7 +4,7 @@
 # One rocprofv3 --pmc pass per counter group (no trace domains), as MI355X_MICROARCH.md prescribes;
 # FETCH_SIZE (3 TCC slots) and WRITE_SIZE (2) cannot share a pass.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$PWD
 OUT=$REPO/gpurun_out/pmc_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT/tmp"

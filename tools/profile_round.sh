@@ -8,7 +8,7 @@
 # rocprofv3 passes: kernel trace + stats per workload; PMC counters in their own passes (no trace
 # domains), as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 MODE=${2:-all}            # "bench": only the bench.py lines (after profiles/roofline_inputs.json was regenerated)
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -47,7 +47,9 @@ python bench.py --workload msm --units 2097152 > "$OUT/bench_msm_2p21.json" 2>/d
 python bench.py --workload msm --units 16777216 --steps 3 --warmup 1 > "$OUT/bench_msm_2p24.json" 2>/dev/null
 python tools/bench_ops.py fe_add,fe_neg,fe_mul,fe_square 16777216 10 > "$OUT/ops.txt" 2>/dev/null
 python tools/bench_ops.py fe_invert,fe_div,fe_sqrt_ratio_i,ed_add,ed_double,ed_neg,ed_eq,ris_eq,ed_is_valid,ed_compress,ed_decompress,ris_compress,ris_decompress,ed_to_affine 1048576 10 >> "$OUT/ops.txt" 2>/dev/null
-python tools/bench_ops.py ed_mul_base,ris_mul_base_compress 4194304 5 >> "$OUT/ops.txt" 2>/dev/null
+python tools/bench_ops.py ed_mul_base,ris_mul_base_compress,ed_mul_base_wnaf5 4194304 5 >> "$OUT/ops.txt" 2>/dev/null
+python bench.py --workload ecdh > "$OUT/bench_ecdh_2p20.json" 2>/dev/null
+python bench.py --workload ecdh --ecdh reference --steps 5 --warmup 2 > "$OUT/bench_ecdh_reference_2p20.json" 2>/dev/null
 python tools/host_path.py 20 2>/dev/null | grep '"auto"\|"1"\|slots' > "$OUT/host_path.txt"
 python tools/host_path.py 22 2>/dev/null | grep '"auto"\|"1"\|slots' >> "$OUT/host_path.txt"
 ls -la "$OUT"
