@@ -1040,7 +1040,7 @@ extern "C" {
 #ifndef ZC_SRC_HASH
 #define ZC_SRC_HASH "unknown"
 #endif
-const char* zc_version(void) { return "zerocaf_hip 0.2 (gfx950, radix-2^29 Montgomery R=2^261) src:" ZC_SRC_HASH; }
+const char* zc_version(void) { return "zerocaf_hip 0.4 (gfx950, radix-2^29 Montgomery R=2^261) src:" ZC_SRC_HASH; }
 const char* zc_last_error(void) { return g_last_error.c_str(); }
 
 int zc_device_count(void)

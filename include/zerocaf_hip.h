@@ -72,7 +72,10 @@ typedef enum zc_status {
 /* ---- context -------------------------------------------------------------- */
 /* devices == NULL / ndev == 0: use the current HIP device.  With ndev > 1, calls on
  * HOST buffers shard the batch into ndev contiguous ranges (independent
- * elements, no exchange step).                                                  */
+ * elements, no exchange step).  The library's tuning knobs (ZC_* environment variables,
+ * INTEGRATION.md section 6; none is needed in production) are read HERE, once, and kept with
+ * the context: contexts with different settings can live side by side, and the environment
+ * of a running process changes nothing for a context that exists.               */
 int zc_ctx_create(const int *devices, int ndev, zc_ctx **out);
 int zc_ctx_destroy(zc_ctx *ctx);
 /* external != 0: launch on the caller's hipStream_t `hip_stream` (e.g.

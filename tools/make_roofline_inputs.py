@@ -136,9 +136,14 @@ def main():
                 rows = [r for r in csv.DictReader(open(st)) if r["Name"].startswith(MSM_STEP_KERNELS)]
                 tot = sum(float(r["TotalDurationNs"]) for r in rows)
                 runs = [r for r in rows if r["Name"].startswith("k_msm_runs_affine")]
-                if runs and tot:
-                    k["runs"][str(units_n)] = {"time_share": round(float(runs[0]["TotalDurationNs"]) / tot, 4), "avg_ms": round(float(runs[0]["AverageNs"]) / 1e6, 4),
-                                               "source": "profiles/%s_raw/kt_msm_%s_kernel_stats.csv (k_msm_runs_affine over the summed kernel time of a step)" % (tag, units_tag)}
+                steps = [r for r in rows if r["Name"].startswith("k_msm_digits")]                 # one per step
+                if runs and tot and steps:
+                    nsteps = int(steps[0]["Calls"])
+                    # window groups launch the kernel once per group: the figure is its time PER STEP, all launches together
+                    k["runs"][str(units_n)] = {"time_share": round(float(runs[0]["TotalDurationNs"]) / tot, 4),
+                                               "avg_ms": round(float(runs[0]["TotalDurationNs"]) / nsteps / 1e6, 4),
+                                               "launches_per_step": round(int(runs[0]["Calls"]) / nsteps, 2),
+                                               "source": "profiles/%s_raw/kt_msm_%s_kernel_stats.csv (k_msm_runs_affine per step, over the summed kernel time of a step)" % (tag, units_tag)}
         for name in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                      "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
                      "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
