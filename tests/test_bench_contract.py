@@ -45,7 +45,7 @@ def test_single_rank_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_single_core"] > 0
     assert d["distinct_devices"] == 1 and len(d["devices"]) == 1 and d["devices"][0]["pci"]
     assert d["config"]["units_per_gpu_per_step"] == 1 << 20 and abs(d["value"] - (1 << 20) / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
-    assert d["config"]["workload"].startswith("2^20 ") and r["schema"] == "useful-work/2" and "-march=native" in c["sample"]
+    assert d["config"]["workload"].startswith("2^20 ") and r["schema"] == "useful-work/2" and "-march=" in c["sample"]
     # the default single-GPU line carries the other BASELINE configs (and the reference's ECDH macro-benchmark) as `secondary`:
     # driver-box numbers for every config, each with its own roofline record and oracle spot check, outside the headline's timing
     sec = {x["name"]: x for x in d["secondary"]}
