@@ -164,3 +164,32 @@ def test_engine_binds_torch_streams_to_the_slot_that_owns_the_tensor():
     finally:
         torch.cuda.current_stream = orig
         e.ctx = None
+
+
+def test_default_engine_knows_its_device_so_the_ownership_check_always_runs():
+    """`Engine()` (no device list) used to keep `_devices = None`, and a tensor on another GPU then got that
+    GPU's torch stream bound to slot 0.  The constructor now always records the context's devices -- torch's current device
+    when torch sees a GPU, else device 0 -- so a foreign tensor is refused before anything is launched.  (No GPU needed: a
+    stand-in for the library records the zc_ctx_create call.)"""
+    import types
+    import dusk_zerocaf_amd as z
+    from dusk_zerocaf_amd.engine import Engine
+    seen = []
+
+    def create(arr, n, out):
+        seen.append([arr[i] for i in range(n)])
+        return 0
+    fake = types.SimpleNamespace(zc_ctx_create=create, zc_ctx_destroy=lambda ctx: 0, zc_last_error=lambda: b"",
+                                 zc_ctx_set_stream_dev=lambda ctx, slot, h, ext: 0)
+    e = Engine(lib=fake)
+    assert seen == [[0]] and e._devices == [0]                  # no GPU visible here: device 0, explicitly
+    import torch
+    orig = torch.cuda.current_stream
+    torch.cuda.current_stream = lambda dev=None: types.SimpleNamespace(cuda_stream=0x1234)
+    try:
+        with pytest.raises(z.ZerocafHipError, match="owns devices"):
+            e._follow_torch_stream(types.SimpleNamespace(device=types.SimpleNamespace(index=1)))
+        e._follow_torch_stream(types.SimpleNamespace(device=types.SimpleNamespace(index=0)))
+    finally:
+        torch.cuda.current_stream = orig
+        e.ctx = None
