@@ -168,8 +168,8 @@ struct DevState {
     hipStream_t aux = nullptr;          // MSM: the point normalisation runs beside the key sort (other priority than `stream`:
                                         // two streams of one priority share a hardware queue here and run one after the other)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t grp[3] = {};            // MSM window groups: the tails of the groups above the lowest one (highest priority)
-    hipEvent_t ev_grp_go[3] = {}, ev_grp_done[3] = {};
+    hipStream_t grp = nullptr;          // MSM window groups: the chains of the groups above the lowest one, one after the other (highest priority)
+    hipEvent_t ev_grp_go[3] = {}, ev_grp_done[3] = {};   // group g's bucket sums are enqueued / its chain is through
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -820,7 +820,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             grp[g].nl0 = (cnt * (size_t)grp[g].nw + grp[g].T - 1) / grp[g].T;
             grp[g].slot0 = lanes_total;
             lanes_total += grp[g].nl0;
-            grp[g].st = g == G - 1 ? D.s() : D.grp[0];       // ONE side stream: streams of one priority share a hardware queue here anyway
+            grp[g].st = g == G - 1 ? D.s() : D.grp;          // ONE side stream: streams of one priority share a hardware queue here anyway
         }
     }
     const size_t spw = ((size_t)1 << (c - 1)) / (size_t)seg;   // segments per window (both powers of two)
@@ -1013,6 +1013,7 @@ DevState* dev_state_of(zc_ctx* ctx, int device)
 // in device memory (*result), everything enqueued on ds.s().
 int msm_shard(DevState& ds, const uint64_t* points, const uint64_t* scalars, size_t cnt, bool on_device, const u64** result)
 {
+    if (int rc = ring_check(ds)) return rc;                  // an asynchronous failure of an earlier windowed-core call surfaces here too
     HIP_TRY(hipSetDevice(ds.device));
     const u64 *dP = points, *dK = scalars;
     if (!on_device) {
@@ -1089,11 +1090,13 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming);
-        for (int g = 0; g < 3 && e == hipSuccess; g++) {
+        if (e == hipSuccess) {
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-            e = hipStreamCreateWithPriority(&ds.grp[g], hipStreamNonBlocking, tune.msm_tail_prio == 0 ? 0 : hi_p);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_grp_go[g], hipEventDisableTiming);
+            e = hipStreamCreateWithPriority(&ds.grp, hipStreamNonBlocking, tune.msm_tail_prio == 0 ? 0 : hi_p);
+        }
+        for (int g = 0; g < 3 && e == hipSuccess; g++) {
+            e = hipEventCreateWithFlags(&ds.ev_grp_go[g], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_grp_done[g], hipEventDisableTiming);
         }
         if (e != hipSuccess) {
@@ -1119,8 +1122,8 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.ev_fork) (void)hipEventDestroy(ds.ev_fork);
         if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
         if (ds.aux) (void)hipStreamDestroy(ds.aux);
+        if (ds.grp) (void)hipStreamSynchronize(ds.grp), (void)hipStreamDestroy(ds.grp);
         for (int g = 0; g < 3; g++) {
-            if (ds.grp[g]) (void)hipStreamSynchronize(ds.grp[g]), (void)hipStreamDestroy(ds.grp[g]);
             if (ds.ev_grp_go[g]) (void)hipEventDestroy(ds.ev_grp_go[g]);
             if (ds.ev_grp_done[g]) (void)hipEventDestroy(ds.ev_grp_done[g]);
         }
@@ -1821,6 +1824,7 @@ int zc_ed_fold_ordered(zc_ctx* ctx, const uint64_t* parts, size_t count, uint64_
     std::lock_guard<std::mutex> lock(ctx->mu);
     DevState* ds = rp == RES_DEVICE ? dev_state_of(ctx, dp) : &ctx->devs[0];
     if (!ds) return fail(ZC_ERR_MIXED_MEM, "device buffers do not belong to a device of this context");
+    if (int rc = ring_check(*ds)) return rc;
     HIP_TRY(hipSetDevice(ds->device));
     if (rp == RES_DEVICE) {
         hipLaunchKernelGGL(zc::k_ed_fold_ordered, dim3(1), dim3(64), 0, ds->s(), (const u64*)parts, count, (const u64*)nullptr, (u64*)out);
