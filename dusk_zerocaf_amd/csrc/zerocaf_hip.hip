@@ -729,6 +729,7 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     p.m = cnt * (size_t)p.W;
     p.nb = (size_t)p.W << (p.c - 1);                      // buckets (digit magnitudes 1 .. 2^(c-1) per window)
     p.seg = tune.msm_seg ? tune.msm_seg : zc::msm_segment_buckets(p.nb);
+    while (p.seg > (1 << (p.c - 1))) p.seg >>= 1;        // a segment never spans windows (ZC_MSM_SEG beside a narrow ZC_MSM_WINDOW)
     p.nseg = p.nb / (size_t)p.seg;
     p.sort = msm_sort_plan(cnt, p.c, p.W, tune);
     p.affine = msm_affine(cnt, tune) && points_aligned16;  // the normalisation moves the point records with 16-byte loads

@@ -1150,7 +1150,7 @@ def test_msm_skewed_digit_distributions(eng, oracle):
 @pytest.mark.parametrize("knobs", [
     dict(ZC_MSM_AFFINE=0), dict(ZC_MSM_AFFINE=0, ZC_MSM_FORK=1), dict(ZC_MSM_FORK=0), dict(ZC_MSM_FORK=1),
     dict(ZC_MSM_RUN_EDGES=4), dict(ZC_MSM_RUN_EDGES=32, ZC_MSM_RUN=16), dict(ZC_MSM_AFFINE_CHUNK=1), dict(ZC_MSM_AFFINE_CHUNK=5, ZC_MSM_SEG=4),
-    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12), dict(ZC_MSM_GROUPS="17,4"), dict(ZC_MSM_GROUPS="12,5,4", ZC_MSM_SEG_QUAD=0),
+    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12), dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=6, ZC_MSM_RUN=128), dict(ZC_MSM_GROUPS="17,4"), dict(ZC_MSM_GROUPS="12,5,4", ZC_MSM_SEG_QUAD=0),
     dict(ZC_MSM_GROUPS="6,5,5,5", ZC_MSM_SEG_QUAD=1 << 20), dict(ZC_MSM_GROUPS="11,6,4", ZC_MSM_TAIL_SIDE=0, ZC_MSM_GROUP_WGS=0),
     dict(ZC_MSM_GROUPS="9,8,4", ZC_MSM_GROUP_LANES=19, ZC_MSM_GROUP_WGS=2, ZC_MSM_TAIL_PRIO=0), dict(ZC_MSM_GROUPS="20,1", ZC_MSM_AFFINE=0), dict(ZC_MSM_REC_STRIDE=96),
     dict(ZC_MSM_REC_STRIDE=96, ZC_MSM_GROUPS="10,11", ZC_MSM_AFFINE_CHUNK=3)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
@@ -1170,6 +1170,8 @@ def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
     with V.tuned(**knobs) as te:
         if "ZC_MSM_GROUPS" in knobs:                              # the split is really in force (it must add up to the windows)
             assert te.msm_plan(n)["window_groups"] == len(knobs["ZC_MSM_GROUPS"].split(",")) and te.msm_plan(n)["windows"] == 21
+        if knobs.get("ZC_MSM_WINDOW") == 6:                       # 32 buckets per window: a 64-bucket segment is cut down to the window
+            assert te.msm_plan(n)["segment_buckets"] == 32 and te.msm_plan(n)["windows"] == 44
         got = te.msm(P, K)
         assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), knobs
         for _ in range(2):                                        # and again: the side stream's events and the workspace are reused

@@ -78,6 +78,11 @@ assert np.array_equal(eng.sc_into_bits(rawk), zc_ref.sc_into_bits(rawk))
 wdt = int(rng.choice([0, 2, 3, 4, 5, 6, 7]))
 both = np.concatenate([sa[:ms], rawk])
 assert np.array_equal(eng.sc_compute_naf(both, wdt), par(zc_ref.sc_compute_naf, len(both), both) if wdt == 0 else zc_ref.sc_compute_naf(both, wdt)), "naf width %d" % wdt
+# window_naf_mul in one launch: the point (sum_i d_i 2^i) B of the ORACLE's digits, canonical and raw scalars alike
+wn = int(rng.integers(2, 8))
+vals = V.limbs_array([sum(int(dg) << i for i, dg in enumerate(row)) % pm.L for row in zc_ref.sc_compute_naf(both, wn).astype(np.int64)])
+baseb = np.tile(base[:1], (len(both), 1))
+assert zc_ref.ed_eq(eng.ed_mul_base_wnaf(both, wn), par(zc_ref.ed_scalar_mul, len(both), baseb, vals)).all(), "window_naf_mul width %d" % wn
 isq, sq = eng.fe_inv_sqrt(a[:ms]); wisq, wsq = zc_ref.fe_inv_sqrt(a[:ms])
 assert np.array_equal(isq, wisq) and np.array_equal(sq, wsq)
 assert np.array_equal(eng.ed_coset4(P[:ms]), zc_ref.ed_coset4(P[:ms]))
