@@ -1,7 +1,8 @@
 // zc_msm.hip.h -- bucket-method (Pippenger) multi-scalar multiplication kernels.
 // Not in the reference: sum_i k_i * P_i is specified through the reference's
-// own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU, one stream,
-// no host synchronisation anywhere:
+// own ops (Mul<Scalar> then Add) and compared as a group element.  Pipeline per GPU on the caller's stream (the
+// normalisation forks onto a second stream beside the sort, the chains of the upper window groups onto a third;
+// events join them), no host synchronisation anywhere:
 //   1. k_msm_digits   : SIGNED c-bit window digits d in (-2^(c-1), 2^(c-1)] of the effective scalar
 //                       (scalar_effective: double_and_add's termination rule), window-major:
 //                       keys[w n + i] = sign << 31 | (|d| - 1), or 2^(c-1) for a zero digit.
@@ -11,9 +12,9 @@
 //                       window << (c-1) | |d| - 1, point index | sign << 31) ordered by bucket, zero
 //                       digits (key 0xFFFFFFFF) behind every bucket
 //   0. k_msm_prepare  : points -> cached form, Montgomery domain.  Large batches: AFFINE records
-//                       (y-x, y+x, 2dxy), 96 bytes, one division-step inversion per lane shared by its
-//                       points (Montgomery's trick), so that a bucket addition costs 7 multiplications;
-//                       small batches: (Y-X, Y+X, Z, 2dT), one 128-byte cache line, 8 multiplications
+//                       (y-x, y+x, 2dxy), 96 bytes of payload at a 128-byte stride (one record per cache line), one
+//                       division-step inversion per lane shared by its points (Montgomery's trick), so that a bucket
+//                       addition costs 7 multiplications; small batches: (Y-X, Y+X, Z, 2dT), 128 bytes, 8 multiplications
 //   3. k_msm_runs     : the bucket sums as a SEGMENTED REDUCTION of the sorted list in fixed-length
 //                       runs: lane j adds the T consecutive entries [jT, (j+1)T) whatever buckets they
 //                       belong to, so every lane does the same work however skewed the digit
@@ -21,16 +22,19 @@
 //                       with n / 2^k points each; one lane per bucket would serialise them).  A bucket
 //                       that lies inside one run is written out directly; a bucket that crosses run
 //                       boundaries leaves one partial sum per run ("edge"), and the edge list -- again
-//                       sorted by key, 2 n W / T entries -- goes through the same kernel until one lane
-//                       holds it all (list lengths shrink by T/2 per level: 6 launches for 2^25 pairs).
-//                       Each point costs one 8-multiplication a = -1 addition against the cached form
-//                       (negated by swapping Y-X / Y+X and negating 2dT when the digit is negative); the
-//                       next record is prefetched straight into LDS (global_load_lds), four waves per SIMD
-//   5. k_msm_segments : running-sum reduction of each window in segments of SEG buckets
-//                       (sum_seg = sum (j + 1) B_{first+j}, acc_seg = sum B)
-//   6. existing kernels: (first mod 2^(c-1)) * acc_seg via k_ed_scalar_mul, k_ed_add,
-//      k_ed_fold_pairs down to one point per window
-//   7. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling
+//                       sorted by key, 2 n W / T entries -- goes through k_msm_runs_edges level by level until
+//                       one lane holds it all (list lengths shrink by 4 per level).  Each point costs one mixed
+//                       addition against the cached record (negated by swapping Y-X / Y+X and negating 2dT when the
+//                       digit is negative); the next record is prefetched straight into LDS (global_load_lds), four
+//                       waves per SIMD.  Shards of 2^21 .. 2^22 pairs launch it once per WINDOW GROUP, top windows first
+//                       (msm_runs_body below; zerocaf_hip.hip: msm_on_device), and the chain of kernels behind a
+//                       group's launch runs on a side stream beside the next group's bucket sums
+//   4. k_msm_segments : one lane per segment of SEG buckets: running sums (acc = sum B, sum = sum (j + 1) B_{first+j}),
+//                       then the product first' * acc and the final addition in the same lane
+//                       (k_msm_segments_quad: four lanes per segment for launches of few segments)
+//   5. k_msm_fold_groups : the segment sums of every window down to one point per window (LDS tree, two launches)
+//   6. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling, continued from the
+//                       result of the window group above
 #pragma once
 #include "zc_kernels.hip.h"
 #include "zc_quad.hip.h"
