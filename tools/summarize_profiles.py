@@ -89,7 +89,7 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     prof = os.path.join(ROOT, "profiles")
     raw = os.path.join(prof, tag + "_raw")
-    shutil.rmtree(raw, ignore_errors=True)
+    shutil.rmtree(raw, ignore_errors=True)        # rewritten from scratch: keep hand-collected experiment records elsewhere (profiles/<tag>_experiments/)
     os.makedirs(raw)
     for f in glob.glob(os.path.join(src, "*.csv")):
         if f.endswith(("_kernel_stats.csv", "_counter_collection.csv")) or f.endswith("_kernel_trace.csv"):
