@@ -566,6 +566,50 @@ ZC_KERNEL void k_msm_fold_groups(const u64* in, u64* out, u32 g)
     if (t == 0) pt_store(out + 20 * (size_t)blockIdx.x, pt_load_raw(mine));
 }
 
+// The same with four lanes per addition (ptm_add_quad: three multiplication latencies per level instead of nine): 64 quads
+// per workgroup, g <= 128 points.  The tree is pure latency -- a few dozen workgroups, one addition per level -- so the quad
+// form takes a third of the time (2^21 pairs in three window groups: 3.46 -> 3.34 ms, four alternating rounds on one box;
+// other sizes unchanged); the intermediate sums stay in the loop's own (Y-X, Y+X, Z, T) form in LDS.
+ZC_DI void ptm_store_raw(u32* __restrict__ o, const ptm& p)
+{
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        o[i] = p.Ym.v[i]; o[9 + i] = p.Yp.v[i]; o[18 + i] = p.Z.v[i]; o[27 + i] = p.T.v[i];
+    }
+}
+ZC_DI ptm ptm_load_raw(const u32* __restrict__ o)
+{
+    ptm p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        p.Ym.v[i] = o[i]; p.Yp.v[i] = o[9 + i]; p.Z.v[i] = o[18 + i]; p.T.v[i] = o[27 + i];
+    }
+    return p;
+}
+ZC_KERNEL void k_msm_fold_groups_quad(const u64* in, u64* out, u32 g)
+{
+    __shared__ u32 sraw[MSM_RAW_WORDS * (ZC_BLOCK / 4)];
+    msm_tail_priority();
+    const int role = threadIdx.x & 3;
+    const u32 q = threadIdx.x >> 2;
+    u32* mine = sraw + MSM_RAW_WORDS * q;
+    const size_t base = (size_t)blockIdx.x * g;
+    u32 live = g / 2;
+    ptm s = ptm_from_pt(pt_identity());
+    if (q < live) {
+        s = ptm_add_quad(ptm_from_pt(pt_load(in + 20 * (base + 2 * q))), ptm_from_pt(pt_load(in + 20 * (base + 2 * q + 1))), role);
+        if (role == 0) ptm_store_raw(mine, s);
+    }
+    while (live > 1) {
+        __syncthreads();
+        live >>= 1;
+        if (q < live) s = ptm_add_quad(ptm_load_raw(mine), ptm_load_raw(mine + MSM_RAW_WORDS * live), role);
+        __syncthreads();
+        if (q < live && role == 0) ptm_store_raw(mine, s);
+    }
+    if (threadIdx.x == 0) pt_store(out + 20 * (size_t)blockIdx.x, ptm_to_pt(s));
+}
+
 // ---------------------------------------------------------------- window combination
 // S = sum_w 2^(c w) S_w by Horner's rule: c doublings and one addition per window, about 250
 // dependent doublings on ONE point, so the step is pure latency.  A quad of lanes shares each

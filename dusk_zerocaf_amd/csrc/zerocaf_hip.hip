@@ -73,6 +73,7 @@ struct Tuning {
     long msm_group_lanes = 0;        // ZC_MSM_GROUP_LANES=l: lanes a window group's bucket-sum launch keeps busy (log2, 15..22)
     int msm_rec_stride = 0;          // ZC_MSM_REC_STRIDE=96/128: stride of the affine records (128: one record per cache line)
     int msm_tail_side = -1;          // ZC_MSM_TAIL_SIDE=0: the groups' chains on the caller's stream, one after the other (A/B: no overlap)
+    int msm_fold_quad = -1;          // ZC_MSM_FOLD_QUAD=0/1: the fold tree with four lanes per addition (default 1)
     long msm_group_wgs = -1;         // ZC_MSM_GROUP_WGS=k: workgroups per CU of the bucket-sum launches that run beside a tail (0: no limit)
 #ifdef ZC_TEST_HOOKS
     bool test_ring_poison = false;   // ZC_TEST_RING_POISON: pretend a wave of every windowed-core launch gave up
@@ -123,6 +124,7 @@ Tuning tuning_from_env()
     t.msm_seg_quad = env_long("ZC_MSM_SEG_QUAD", 0, 1 << 24, -1);
     t.msm_group_lanes = env_long("ZC_MSM_GROUP_LANES", 15, 22, 0);
     t.msm_group_wgs = env_long("ZC_MSM_GROUP_WGS", 0, 8, -1);
+    t.msm_fold_quad = (int)env_long("ZC_MSM_FOLD_QUAD", 0, 1, -1);
     t.msm_tail_side = (int)env_long("ZC_MSM_TAIL_SIDE", 0, 1, -1);
     {
         const long v = env_long("ZC_MSM_REC_STRIDE", 96, 128, 0);
@@ -942,11 +944,13 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 hipLaunchKernelGGL(zc::k_msm_segments, dim3(grid_for(nsegg)), dim3(zc::ZC_BLOCK), 0, st, (const zc::u32*)(buckets + b0 * zc::MSM_RAW_WORDS),
                                    (const uint8_t*)(present + b0), cur, nsegg, c, seg);
             // fold every window's segment sums (a power of two per window) to one point per window:
-            // one workgroup per group of up to 512 points, two launches at most
+            // one workgroup per group of up to 128 points (four lanes per addition) or 512, two launches
             size_t left = nsegg;
+            const bool fold_quad = tune.msm_fold_quad != 0;      // ZC_MSM_FOLD_QUAD=0: one lane per addition, 512 points per workgroup
             while (left > (size_t)gr.nw) {
-                const size_t fg = std::min<size_t>(512, left / (size_t)gr.nw);
-                hipLaunchKernelGGL(zc::k_msm_fold_groups, dim3((unsigned)(left / fg)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)cur, nxt, (zc::u32)fg);
+                const size_t fg = std::min<size_t>(fold_quad ? 128 : 512, left / (size_t)gr.nw);
+                hipLaunchKernelGGL(fold_quad ? zc::k_msm_fold_groups_quad : zc::k_msm_fold_groups, dim3((unsigned)(left / fg)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)cur, nxt,
+                                   (zc::u32)fg);
                 left /= fg;
                 std::swap(cur, nxt);
             }

@@ -1152,7 +1152,7 @@ def test_msm_skewed_digit_distributions(eng, oracle):
     dict(ZC_MSM_RUN_EDGES=4), dict(ZC_MSM_RUN_EDGES=32, ZC_MSM_RUN=16), dict(ZC_MSM_AFFINE_CHUNK=1), dict(ZC_MSM_AFFINE_CHUNK=5, ZC_MSM_SEG=4),
     dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12), dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=6, ZC_MSM_RUN=128), dict(ZC_MSM_GROUPS="17,4"), dict(ZC_MSM_GROUPS="12,5,4", ZC_MSM_SEG_QUAD=0),
     dict(ZC_MSM_GROUPS="6,5,5,5", ZC_MSM_SEG_QUAD=1 << 20), dict(ZC_MSM_GROUPS="11,6,4", ZC_MSM_TAIL_SIDE=0, ZC_MSM_GROUP_WGS=0),
-    dict(ZC_MSM_GROUPS="9,8,4", ZC_MSM_GROUP_LANES=19, ZC_MSM_GROUP_WGS=2, ZC_MSM_TAIL_PRIO=0), dict(ZC_MSM_GROUPS="20,1", ZC_MSM_AFFINE=0), dict(ZC_MSM_REC_STRIDE=96),
+    dict(ZC_MSM_GROUPS="9,8,4", ZC_MSM_GROUP_LANES=19, ZC_MSM_GROUP_WGS=2, ZC_MSM_TAIL_PRIO=0), dict(ZC_MSM_GROUPS="20,1", ZC_MSM_AFFINE=0), dict(ZC_MSM_REC_STRIDE=96), dict(ZC_MSM_FOLD_QUAD=0), dict(ZC_MSM_FOLD_QUAD=0, ZC_MSM_GROUPS="8,8,5", ZC_MSM_SEG=4),
     dict(ZC_MSM_REC_STRIDE=96, ZC_MSM_GROUPS="10,11", ZC_MSM_AFFINE_CHUNK=3)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
     """Every MSM path a ZC_* knob can select in the shipped library (projective 128-byte records at a size where the

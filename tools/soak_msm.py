@@ -20,7 +20,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 eng = z.Engine()
 zc_ref.build()
 KNOBS = ("ZC_MSM_WINDOW", "ZC_MSM_AFFINE", "ZC_MSM_SORT_PACKED", "ZC_MSM_SORT_BIG", "ZC_MSM_RUN", "ZC_MSM_SORT_G", "ZC_MSM_AFFINE_CHUNK",
-         "ZC_MSM_GROUPS", "ZC_MSM_REC_STRIDE", "ZC_MSM_SEG", "ZC_MSM_SEG_QUAD", "ZC_MSM_GROUP_LANES", "ZC_MSM_TAIL_SIDE", "ZC_MSM_RUN_EDGES", "ZC_MSM_FORK")
+         "ZC_MSM_GROUPS", "ZC_MSM_REC_STRIDE", "ZC_MSM_SEG", "ZC_MSM_SEG_QUAD", "ZC_MSM_GROUP_LANES", "ZC_MSM_TAIL_SIDE", "ZC_MSM_RUN_EDGES", "ZC_MSM_FORK", "ZC_MSM_FOLD_QUAD")
 for seed in range(first, first + count):
     t0 = time.time()
     rng = np.random.default_rng(0xB0C4E7 + seed)
@@ -51,6 +51,8 @@ for seed in range(first, first + count):
         knobs["ZC_MSM_RUN_EDGES"] = int(rng.choice([4, 6, 8, 16, 32]))
     if rng.random() < 0.2:
         knobs["ZC_MSM_FORK"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        knobs["ZC_MSM_FOLD_QUAD"] = 0
     for k, v in knobs.items():
         os.environ[k] = str(v)
     if rng.random() < 0.6:
