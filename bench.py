@@ -319,6 +319,8 @@ def roofline_for(env, run, kern_avg_s):
     inp, stale = roofline_inputs()
     kkey = wl if not (wl == "scalar_mul" and mode == "fast") else "scalar_mul_fast"
     kin = (inp or {}).get("kernels", {}).get(kkey, {}) if not stale else {}
+    if wl == "scalar_mul" and run["bits"] != 252:
+        kin = {}                                    # the PMC profile was taken on 252-bit scalars: no issued-work fields for another domain
     if kin.get("hbm_bytes_per_unit") is not None and kin.get("units_per_call") in (None, n):
         hbm["traffic"] = round(kin["hbm_bytes_per_unit"] * n)
         hbm["traffic_source"] = inp.get("source")
@@ -614,7 +616,20 @@ def mode_label(wl, mode, ecdh):
 # the other BASELINE configs + the reference's macro-benchmark, run after the headline in the default single-GPU line:
 # (workload, units, scalar bits, timed steps, warm-up steps, oracle sample per host thread)
 SECONDARY = [("fe_mul", 1 << 24, 252, 20, 30, 1 << 14), ("fe_invert", 1 << 20, 252, 20, 5, 1 << 10), ("ristretto", 1 << 22, 252, 3, 1, 128),
-             ("msm", 1 << 21, 249, 10, 3, 256), ("ecdh", 1 << 20, 249, 3, 1, 48)]
+             ("msm", 1 << 21, 249, 10, 3, 256), ("ecdh", 1 << 20, 249, 3, 1, 48),
+             # the headline once more on the reference's own Scalar::random domain (< 2^249, SURVEY 8d config 3: "report both")
+             ("scalar_mul", 1 << 20, 249, 10, 2, 1 << 10)]
+
+
+def secondary_name(wl, bits):
+    return "scalar_mul_s%d" % bits if wl == "scalar_mul" else wl
+
+
+def summary_line(name, rec):
+    """One short line per config for the driver's 2000-character tail: rate, time per step, roofline fraction and bound, parity."""
+    rf = rec["roofline"]
+    return "secondary %s: %.4g %s, %.4f ms/step, frac %s of %s roof, parity %s" % (
+        name, rec["value"], rec["unit"], rec["ms_per_step"], rf.get("frac"), rf.get("bound"), rec["parity_spot_check"])
 
 
 def secondary_runs(env):
@@ -628,7 +643,7 @@ def secondary_runs(env):
         fold_ok = msm_fold_check(env, run) if wl == "msm" else None
         rf = roofline_for(env, run, kern)
         checked, cpu = check_and_baseline(env, run, per_core * cores, True, fold_ok)
-        rec = {"workload": workload_label(wl, n, bits), "name": wl, "units": n, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+        rec = {"workload": workload_label(wl, n, bits), "name": secondary_name(wl, bits), "units": n, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
                "value": round(n * steps / dt, 1), "unit": WORKLOADS[wl]["unit"], "mode": mode_label(wl, "strict", "wire"), "roofline": rf,
                "parity_spot_check": checked, "parity_sample_units": per_core * cores if wl != "fe_mul" else min(n, per_core * cores),
                "cpu_value": cpu["value"] if cpu else None, "cpu_cores": cores, "wall_s": None}
@@ -639,8 +654,54 @@ def secondary_runs(env):
         env.torch.cuda.empty_cache()
         rec["wall_s"] = round(time.perf_counter() - t_all, 2)
         out.append(rec)
-        log("secondary %s: %.4f ms per step, parity %s (%.1f s)" % (wl, rec["ms_per_step"], checked, rec["wall_s"]))
+        log("secondary %s: %.4f ms per step, parity %s (%.1f s)" % (rec["name"], rec["ms_per_step"], checked, rec["wall_s"]))
     return out
+
+
+def self_launch(args, json_fd):
+    """`python bench.py --gpus N` with no launcher environment: start the N ranks here, one device each, the way
+    torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, rendezvous on 127.0.0.1), pass rank 0's ONE
+    JSON line through to stdout and fail when any rank fails.  Fail closed: fewer than N visible devices is an error
+    (unless the one-device test hook ZC_BENCH_DEVICE is set), never a smaller measurement."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not os.environ.get("ZC_BENCH_DEVICE"):
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit("bench.py: --gpus %d but %d visible device%s: refusing to time fewer GPUs than asked for"
+                             % (n, have, "" if have == 1 else "s"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else 2, stderr=2))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("ZC_BENCH_LAUNCH_TIMEOUT", "1800"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:            # one rank down (or the time is up): the others would wait in a barrier for ever
+            failed = "rank %s failed" % bad if bad else "timed out"
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(10)
+    lines = [l for l in (got[0] if got else b"").decode(errors="replace").splitlines() if l.strip()]
+    if failed or any(rcs) or len(lines) != 1:
+        raise SystemExit("bench.py: self-launched ranks failed (%s; exit codes %s; %d stdout lines from rank 0)" % (failed, rcs, len(lines)))
+    os.write(json_fd, (lines[0] + "\n").encode())
 
 
 def main():
@@ -668,12 +729,19 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' lines in the default single-GPU run")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, json_fd)            # plain `python bench.py --gpus N`: launch the N ranks ourselves
+
     import torch                                   # before the HIP library: one HIP runtime per process
     import torch.distributed as dist
     import dusk_zerocaf_amd as z
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:                           # fail closed: never time another number of GPUs than asked for
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -689,8 +757,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world:
-        log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
 
     eng = z.Engine([local])
     stream = torch.cuda.current_stream()
@@ -772,6 +838,7 @@ def main():
                    "sharding": "contiguous ranges; ncclAllGather of one 160-byte partial sum per rank inside libzerocaf_hip.so + ordered fold kernel"
                                if wl == "msm" else "contiguous ranges, no collective",
                    "mode": mode_label(wl, args.mode, args.ecdh)},
+        "secondary_summary": None,
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_spot_check": checked,
@@ -783,8 +850,17 @@ def main():
         line["rccl_ranks"] = rccl_ranks                      # ncclCommCount of the library's own communicator (None: gloo test hook)
         line["msm_result_is_fold_of_shard_partials"] = msm_fold_ok
     if secondary is not None:
+        # every config's time and roofline fraction where the driver's record keeps them: a compact block in front of
+        # `roofline`, the same block inside it, and (last thing on stderr) one short line per config
+        line["secondary_summary"] = {x["name"]: [x["ms_per_step"], x["roofline"].get("frac"), x["roofline"].get("bound")] for x in secondary}
+        roofline["secondary"] = {x["name"]: {"ms_per_step": x["ms_per_step"], "value": x["value"], "unit": x["unit"], "frac": x["roofline"].get("frac"),
+                                             "bound": x["roofline"].get("bound"), "parity": x["parity_spot_check"]} for x in secondary}
         line["secondary"] = secondary
+    else:
+        del line["secondary_summary"]
     os.write(json_fd, (json.dumps(line) + "\n").encode())
+    for x in secondary or []:
+        log(summary_line(x["name"], x))
     if world > 1:
         dist.destroy_process_group()
 

@@ -49,8 +49,8 @@ def test_single_rank_line():
     # the default single-GPU line carries the other BASELINE configs (and the reference's ECDH macro-benchmark) as `secondary`:
     # driver-box numbers for every config, each with its own roofline record and oracle spot check, outside the headline's timing
     sec = {x["name"]: x for x in d["secondary"]}
-    assert list(sec) == ["fe_mul", "fe_invert", "ristretto", "msm", "ecdh"]
-    assert [sec[k]["units"] for k in sec] == [1 << 24, 1 << 20, 1 << 22, 1 << 21, 1 << 20]
+    assert list(sec) == ["fe_mul", "fe_invert", "ristretto", "msm", "ecdh", "scalar_mul_s249"]
+    assert [sec[k]["units"] for k in sec] == [1 << 24, 1 << 20, 1 << 22, 1 << 21, 1 << 20, 1 << 20]
     for k, x in sec.items():
         lg = x["units"].bit_length() - 1
         assert x["parity_spot_check"] is True and x["workload"].startswith("2^%d" % lg), k
@@ -60,6 +60,23 @@ def test_single_rank_line():
     assert sec["msm"]["msm_result_is_fold_of_shard_partials"] is True and sec["msm"]["rccl_ranks"] == 1
     assert sec["msm"]["roofline"]["useful"]["plan"]["window_groups"] == 3 and sec["msm"]["roofline"]["useful"]["multiplications_per_bucket_addition"] == 7
     assert sec["ecdh"]["roofline"]["bound"] == "valu_int_mul"
+    # the reference's own Scalar::random domain next to the 252-bit headline: fewer formula evaluations per unit, same kernel
+    s249 = sec["scalar_mul_s249"]["roofline"]
+    assert 365 < s249["useful"]["formula_evaluations_per_unit"] < r["useful"]["formula_evaluations_per_unit"] and "issued" not in s249
+    # where the driver's record keeps the other configs: a compact block in FRONT of `roofline` (its fixed keys and a
+    # 2000-character tail survive), the same numbers inside `roofline`, and one short stderr line per config, printed last
+    keys = list(d)
+    assert keys.index("secondary_summary") < keys.index("roofline") < keys.index("secondary")
+    assert list(d["secondary_summary"]) == list(sec) == list(r["secondary"])
+    for k, (ms, frac, bound) in d["secondary_summary"].items():
+        assert ms == sec[k]["ms_per_step"] and frac == sec[k]["roofline"]["frac"] and bound == sec[k]["roofline"]["bound"], k
+        assert r["secondary"][k]["frac"] == frac and r["secondary"][k]["parity"] is True
+    # (RCCL's banner, buffered on fd 1, is flushed behind them at exit: five short lines)
+    assert all("secondary" in l or "version" in l or l.startswith(("Hostname", "Librccl")) for l in out.stderr.splitlines()[-(len(sec) + 5):] if l.strip())
+    tail = [l for l in out.stderr.splitlines() if l.startswith("secondary ") and "ms/step" in l]
+    assert len(tail) == len(sec) and len("\n".join(tail)) < 1200 and len(out.stderr[out.stderr.index(tail[0]):]) < 1900, tail
+    for k, l in zip(sec, tail):
+        assert l.startswith("secondary %s: " % k) and "frac %s of %s roof" % (sec[k]["roofline"]["frac"], sec[k]["roofline"]["bound"]) in l and l.endswith("parity True"), l
 
 
 @pytest.mark.gpu
@@ -110,6 +127,50 @@ def test_two_ranks_launched_like_the_driver(workload, units):
     assert d["distinct_devices"] == 1 and d["kernel_avg_ms_ranks"]["min"] <= d["kernel_avg_ms_ranks"]["max"]
     if workload == "msm":
         assert d["msm_result_is_fold_of_shard_partials"] is True and "rccl_ranks" in d
+
+
+@pytest.mark.gpu
+def test_plain_python_launch_starts_the_ranks_itself():
+    """The driver's observed invocation is plain `python3 bench.py --gpus N ...` (BENCH_r04.json.cmd): with no launcher
+    environment bench.py starts the N ranks itself and still prints ONE line with n_gpus = N (one-device test hooks here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZC_BENCH_BACKEND="gloo", ZC_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--units", str(1 << 18)],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _one_json_line(out.stdout)
+    assert d["n_gpus"] == 2 and [x["rank"] for x in d["devices"]] == [0, 1] and d["parity_spot_check"] is True
+    assert abs(d["value"] - 2 * (1 << 18) / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+
+
+@pytest.mark.gpu
+def test_more_gpus_than_devices_fails_closed():
+    """`--gpus N` on a box with fewer than N devices must not come back as a smaller measurement: non-zero exit, nothing on stdout."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ZC_BENCH_DEVICE", "ZC_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0 and out.stdout.strip() == "" and "visible device" in out.stderr, (out.returncode, out.stdout[-300:], out.stderr[-600:])
+    # under a launcher: as many ranks as the launcher started, or an error -- never "using WORLD_SIZE"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, RANK="0", WORLD_SIZE="1"))
+    assert out.returncode != 0 and out.stdout.strip() == "" and "WORLD_SIZE" in out.stderr
+
+
+def test_gpus_flag_fails_closed_without_a_gpu():
+    """CPU tier: the argument checks come before anything touches a device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ZC_BENCH_DEVICE", "ZC_BENCH_BACKEND")}
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices: --gpus 2 is a valid request here")
+    run = lambda a, e: subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + a, capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    out = run(["--gpus", "2"], env)
+    assert out.returncode != 0 and out.stdout == "" and "visible device" in out.stderr, out.stderr[-500:]
+    out = run(["--gpus", "1"], dict(env, RANK="0", WORLD_SIZE="2"))
+    assert out.returncode != 0 and out.stdout == "" and "WORLD_SIZE is 2" in out.stderr, out.stderr[-500:]
+    out = run(["--gpus", "0"], env)
+    assert out.returncode != 0 and out.stdout == ""
 
 
 @pytest.mark.gpu
