@@ -280,14 +280,10 @@ ZC_DI fe fe_inverse_divsteps(const fe& a)
 }
 
 // a^-1 in the Montgomery domain (a R -> a^-1 R; 0 -> 0): same value as the reference's Savas-Koc
-// inverse (field.rs:854-925) and as a^(p-2) (fp_pow_inv, kept for the A/B: -DZC_INVERT_FERMAT)
+// inverse (field.rs:854-925) and as a^(p-2) (fp_pow_inv; the A/B against it: tools/debug/probes/)
 ZC_DI fe fp_invert(const fe& a)
 {
-#ifdef ZC_INVERT_FERMAT
-    return fp_pow_inv(a);
-#else
     return mont_to<FP>(fe_inverse_divsteps<FP>(fp_canon(a)));
-#endif
 }
 
 // |x| by the reference's sign rule: negate when canonical value > (p-1)/2
@@ -1017,19 +1013,8 @@ ZC_DI pt fast_window_loop(const TABLE table, const int8_t* __restrict__ dig, int
         const int d = dig[i * stride];
         const int mag = d < 0 ? -d : d;
         niels c = niels_identity();
-#ifdef ZC_FAST_PROBE_AFFINE    // timing probe only (wrong results): what affine table entries would save in this loop -- 96 bytes per
-                               // entry and the 7-multiplication addition -- WITHOUT the normalisation that would have to pay for it
-        if (mag != 0) {
-            const uint4* v = reinterpret_cast<const uint4*>(table.entry(mag - 1));
-            c.ymx = unpack256(v[0], v[1]);
-            c.ypx = unpack256(v[2], v[3]);
-            c.t2d = unpack256(v[4], v[5]);
-        }
-        Q = pt_add_cached<ILP, true>(Q, niels_cond_neg(d < 0, c));
-#else
         if (mag != 0) c = niels_load(table.entry(mag - 1));
         Q = pt_add_cached<ILP>(Q, niels_cond_neg(d < 0, c));
-#endif
     }
     return Q;
 }

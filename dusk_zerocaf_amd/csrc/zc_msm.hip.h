@@ -287,11 +287,7 @@ ZC_DI void msm_flush(u32 key, const pt& sum, bool seg_first, bool seg_last, u32 
             raw_store_zero(dst + MSM_RAW_WORDS);
         }
     }
-#ifndef ZC_MSM_PROBE_NOFLUSH     // timing probe only: the sums are dropped
     pt_store_raw(dst, sum);
-#else
-    if (sum.X.v[0] == 0x12345678u && sum.Y.v[3] == 0x1357u) pt_store_raw(dst, sum);
-#endif
 }
 
 // Level 0 of the segmented reduction (see the file header): the sorted (key, point index | sign << 31)
@@ -342,11 +338,7 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     const u32 prev_key = lo > 0 ? pairs[lo - 1].x : none;
     const u32 next_key = hi < len ? pairs[hi].x : none;
     auto fetch = [&](u32 v) {
-#ifdef ZC_MSM_PROBE_NOGATHER   // timing probe only (wrong sums): every gather hits one of 256 cache-resident records
-        const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)rec_words * (size_t)(v & 0xFFu));
-#else
         const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)rec_words * (size_t)(v & 0x7FFFFFFFu));
-#endif
 #pragma unroll
         for (int q = 0; q < PIECES; q++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q),
@@ -357,24 +349,6 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     fetch(vcur);
     uint2 nxt = (lo + 1 < hi) ? pairs[lo + 1] : make_uint2(none, 0);
     bool first = true;
-#ifdef ZC_MSM_PROBE_PURE        // timing probe only (wrong sums): the additions alone -- one record, no loads, waits or LDS inside the loop
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    niels q0;
-    q0.ymx = unpack256(base[0 * 64 + lane], base[1 * 64 + lane]);
-    q0.ypx = unpack256(base[2 * 64 + lane], base[3 * 64 + lane]);
-    q0.z = fe_zero();
-    q0.t2d = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
-    for (u32 e = lo; e < hi; e++) {
-        acc = pt_add_cached<ZC_MSM_ACC_ILP, AFFINE>(acc, niels_cond_neg((e & 1) != 0, q0));
-        const bool last = e + 1 == hi;
-        if (last || (e & 31) == 31) {
-            msm_flush(cur_key, acc, first, last, prev_key, next_key, sj, nbuckets, buckets_raw, present, next_keys, next_recs);
-            acc = pt_identity();
-            first = false;
-        }
-    }
-    return;
-#endif
     for (u32 e = lo; e < hi; e++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         niels q;

@@ -382,9 +382,6 @@ ZC_DI void msm_sort_scatter_body(const u32* __restrict__ in, void* __restrict__ 
                     else bin = msm_sort_bin(p, k);
                 }
                 gp[r] = goff[bin] + j;
-#ifdef ZC_SORT_PROBE_SEQWRITE     // timing probe only (wrong order): the tile goes out in one piece
-                gp[r] = w * p.n + (u32)lo + j;
-#endif
             }
 #pragma unroll
             for (int r = 0; r < 8; r++)
