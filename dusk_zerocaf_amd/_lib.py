@@ -80,7 +80,7 @@ SIGNATURES = {
     "zc_ed_mul_base_wnaf": [_u64p, C.c_uint, _u64p, _n],
     "zc_msm": [_u64p, _u64p, _n, _u64p],
     "zc_msm_partial": [_u64p, _u64p, _n, _u64p],
-    "zc_msm_plan": [_n, C.c_int, C.POINTER(C.c_int32)],
+    "zc_msm_plan": [_n, C.c_int, C.POINTER(C.c_int32), C.c_int],
     "zc_ed_fold_ordered": [_u64p, _n, _u64p],
     "zc_msm_sharded": [_u64p, _u64p, _n, _u64p],
     "zc_comm_init": [_u8p, C.c_int, C.c_int],
@@ -88,7 +88,7 @@ SIGNATURES = {
     "zc_comm_size": [C.POINTER(C.c_int)],
     "zc_ctx_set_stream_dev": [C.c_int, C.c_void_p, C.c_int],
 }
-CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_set_stream", "zc_ctx_synchronize",
+CONTEXT_SYMBOLS = ["zc_ctx_create", "zc_ctx_destroy", "zc_ctx_device", "zc_ctx_device_count", "zc_ctx_set_stream", "zc_ctx_synchronize",
                    "zc_device_count", "zc_last_error", "zc_version", "zc_host_register", "zc_host_unregister",
                    "zc_comm_unique_id"]
 ALL_SYMBOLS = CONTEXT_SYMBOLS + list(SIGNATURES)
@@ -127,6 +127,8 @@ def _bind(path: str) -> C.CDLL:
     lib.zc_ctx_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_ctx)]
     lib.zc_ctx_create.restype = C.c_int
     lib.zc_ctx_destroy.argtypes = [_ctx]
+    lib.zc_ctx_device.argtypes = [_ctx, C.c_int]
+    lib.zc_ctx_device_count.argtypes = [_ctx]
     lib.zc_ctx_set_stream.argtypes = [_ctx, C.c_void_p, C.c_int]
     lib.zc_ctx_synchronize.argtypes = [_ctx]
     lib.zc_device_count.restype = C.c_int
@@ -166,7 +168,7 @@ def load_test_hooks() -> C.CDLL:
     global _test_lib
     if _test_lib is None:
         if not os.path.exists(TEST_LIB_PATH):
-            raise ZerocafHipError("libzerocaf_hip_test.so is missing: build it with `python -m dusk_zerocaf_amd.build`")
+            raise ZerocafHipError("libzerocaf_hip_test.so is missing: build it with `python -m dusk_zerocaf_amd.build --test-hooks`")
         _share_hip_runtime_with_torch()
         _test_lib = _bind(TEST_LIB_PATH)
         _test_lib.zc_test_msm_sort.argtypes = [_ctx, _u64p, _n, C.c_int, C.c_void_p]

@@ -64,13 +64,14 @@ def _stale(lib: str) -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """libzerocaf_hip.so (the product) and libzerocaf_hip_test.so (the same sources with -DZC_TEST_HOOKS: the fault
-    injection knobs and the sort-stage hook the GPU test tier uses; never loaded by the product path).  The two
-    hipcc runs go side by side."""
+def build(force: bool = False, verbose: bool = False, test_hooks: bool = False) -> str:
+    """libzerocaf_hip.so (the product) and, with test_hooks=True (the test tier and __graft_entry__.build() ask for it;
+    `--test-hooks` on the command line), libzerocaf_hip_test.so: the same sources with -DZC_TEST_HOOKS -- the fault
+    injection knobs, the path forcers and the sort-stage hook the GPU test tier uses; never loaded by the product
+    path.  The two hipcc runs go side by side."""
     build_ubench(force, verbose)
     jobs = []
-    for lib, extra in ((LIB, []), (TEST_LIB, ["-DZC_TEST_HOOKS"])):
+    for lib, extra in ((LIB, []), (TEST_LIB, ["-DZC_TEST_HOOKS"]))[:2 if test_hooks else 1]:
         if not force and not _stale(lib):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", lib,
@@ -103,4 +104,4 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
         sys.exit(0)
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, test_hooks="--test-hooks" in sys.argv))

@@ -508,6 +508,42 @@ ZC_KERNEL void k_ed_double(const u64* p, u64* out, size_t n)
     const pt a = pt_load_plain(p + 20 * i);
     pt_store_plain_r3(out + 20 * i, pt_add(a, a));
 }
+// The same three with the records staged through LDS (16-byte aligned arrays).  A lane's 160-byte record is strided in
+// memory: read per lane it takes twenty 8-byte loads that each touch a cache line of their own, the wave's working set
+// (64 x 160 bytes per operand, three waves per SIMD) is far beyond the L1, and every line comes in from the L2 piece by
+// piece.  Staged, the block's 256 records (40 KB, contiguous) move with coalesced 16-byte loads and stores, one operand
+// after the other through ONE 40 KB buffer (four workgroups per CU; the kernels hold three waves per SIMD anyway), and
+// the results leave the same way.  Same formulas, same limbs.
+template <int OP>                       // 0: add, 1: sub, 2: double
+ZC_DI void ed_binop_staged(const u64* p, const u64* q, u64* out, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) u64 sp[ZC_BLOCK * 20];
+    const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
+    const int cnt = (int)((n - base < (size_t)ZC_BLOCK) ? (n - base) : (size_t)ZC_BLOCK);
+    const int t = threadIdx.x;
+    coop_load40<false>(sp, p + 20 * base, cnt * 4);         // a point = four 40-byte records
+    __syncthreads();
+    pt a = pt_identity(), b;
+    if (t < cnt) a = pt_load_plain(sp + 20 * t);
+    if (OP != 2) {
+        __syncthreads();                                     // every lane has its first operand: the buffer takes the second
+        coop_load40<false>(sp, q + 20 * base, cnt * 4);
+        __syncthreads();
+        b = pt_identity();
+        if (t < cnt) b = pt_load_plain(sp + 20 * t);
+        if (OP == 1) b = pt_neg(b);                          // edwards.rs:503-531: add of the negated rhs (a = -1: same values)
+    } else {
+        b = a;
+    }
+    const pt r = pt_add(a, b);
+    __syncthreads();                                         // ... and then the results
+    if (t < cnt) pt_store_plain_r3(sp + 20 * t, r);
+    __syncthreads();
+    coop_store40<false>(out + 20 * base, sp, cnt * 4);
+}
+ZC_KERNEL void k_ed_add_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<0>(p, q, out, n); }
+ZC_KERNEL void k_ed_sub_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<1>(p, q, out, n); }
+ZC_KERNEL void k_ed_double_staged(const u64* p, u64* out, size_t n) { ed_binop_staged<2>(p, nullptr, out, n); }
 ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();
@@ -664,10 +700,9 @@ ZC_KERNEL void k_ed_scalar_mul_bcast(const u64* p, scalar_arg k, u64* out, size_
     if (valid) pt_store(out + 20 * i, Q);
 }
 
-// k_stride = 5 (one scalar per point).
-// idx != nullptr: batch-wide cost-sorted permutation (k_sm_cost_*); otherwise block-local ranking.
+// k_stride = 5 (one scalar per point).  The block's 256 scalars are ranked by cost in LDS (block_cost_rank).
 template <bool ILP>
-ZC_DI void ed_scalar_mul_body(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
+ZC_DI void ed_scalar_mul_body(const u64* p, const u64* k, size_t k_stride, u64* out, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
     __shared__ u32 skey[ZC_BLOCK];
@@ -676,28 +711,28 @@ ZC_DI void ed_scalar_mul_body(const u64* p, const u64* k, size_t k_stride, u64* 
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
-    const size_t own = valid ? (idx ? (size_t)idx[i] : i) : 0;
+    const size_t own = valid ? i : 0;
     u64 l[5];
     load_scalar(l, k + k_stride * own);
     int nbits;
     scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     if (!valid) nbits = 0;
     int e = tid;
-    if (!idx && k_stride != 0) {
+    if (k_stride != 0) {
         snb[tid] = nbits;
         e = block_cost_rank(skey, sperm, valid ? scalar_cost(l) : 0);
         nbits = snb[e];
     }
     const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
-    const bool run = idx ? valid : (base + e < n);
-    const size_t ii = idx ? own : (run ? base + e : 0);
+    const bool run = base + e < n;
+    const size_t ii = run ? base + e : 0;
     const pt P = pt_load(p + 20 * ii);
     const pt Q = scalar_mul_unified<ILP>(P, sk + e, ZC_BLOCK, run ? nbits : 0);
     if (run) pt_store(out + 20 * ii, Q);
 }
-ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
+ZC_KERNEL void k_ed_scalar_mul(const u64* p, const u64* k, size_t k_stride, u64* out, size_t n)
 {
-    ed_scalar_mul_body<false>(p, k, k_stride, out, idx, n);
+    ed_scalar_mul_body<false>(p, k, k_stride, out, n);
 }
 // Persistent waves for large batches (the headline shape).  A grid of 3 workgroups per CU stays
 // resident; every WAVE, on its own, pulls the next tile of 64 elements from an atomic counter until
@@ -736,9 +771,9 @@ ZC_KERNEL void k_ed_scalar_mul_pw(const u64* p, const u64* k, u64* out, const u3
     }
 }
 // the same for launches of at most a few hundred workgroups (one wave per SIMD): independent-chain multiplier
-ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride, u64* out, const u32* idx, size_t n)
+ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride, u64* out, size_t n)
 {
-    ed_scalar_mul_body<true>(p, k, k_stride, out, idx, n);
+    ed_scalar_mul_body<true>(p, k, k_stride, out, n);
 }
 
 // ---- fast (non-strict) scalar multiplication ---------------------------------------------
@@ -764,8 +799,8 @@ ZC_KERNEL void k_ed_scalar_mul_small(const u64* p, const u64* k, size_t k_stride
 //     (`sc1`: past the L1 of the CU) -- the per-XCD L2 they meet in is coherent for its own CUs;
 //   * a holder never waits for a later ticket, so the waits cannot cycle; the spin is bounded anyway: a wave that
 //     has polled for ~4 s GIVES UP: it sets the device's error word (pinned host memory; its device address is
-//     parked behind the ring state at RING_ERR_WORD), touches no table slot, never publishes its generation (its
-//     successors on that slot give up in turn: fail closed), writes POISON into the rows it owns (limbs / bytes of
+//     parked behind the ring state at RING_ERR_WORD), touches no table slot, never publishes its generation but marks
+//     the slot DEAD (its successors on that slot give up at their first poll: fail closed, without waiting), writes POISON into the rows it owns (limbs / bytes of
 //     all ones, ok = 0) and ends.  The context stays usable: the host reports ZC_ERR_HIP at the next entry point
 //     or synchronisation that touches the device (zerocaf_hip.hip: ring_check; no trap, so no sticky HIP error).
 // Invariants the host side keeps (fast_ring): ONE stream per device state orders every user of the ring;
@@ -782,6 +817,7 @@ constexpr u32 RING_TICKET_STRIDE = 32;            // one 128-byte line per XCD's
 constexpr u32 RING_STATE_WORDS = RING_XCDS * RING_TICKET_STRIDE + RING_XCDS * RING_SLOTS;   // zeroed per launch
 constexpr u32 RING_ERR_WORD = RING_STATE_WORDS;    // behind them (two words, written once by the host): device address of the error word
 constexpr u32 RING_ALLOC_WORDS = RING_STATE_WORDS + 32;
+constexpr u32 RING_SLOT_DEAD = 0xFFFFFFFFu;       // flag word of a slot whose queue gave up (a generation count never gets there: < 2^19)
 constexpr size_t RING_TABLE_BYTES = (size_t)RING_XCDS * RING_SLOTS * 64 * 1024;
 
 // The lane's number, computed afresh wherever it is asked for: `volatile` keeps the compiler from sharing
@@ -826,12 +862,17 @@ ZC_DI ring_table ring_acquire(u32* __restrict__ table, u32* __restrict__ state, 
         u32 spins = 0;
         for (;;) {
             const u32 f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(state + flag_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (f >= gen) break;
+            if (f >= gen && f != RING_SLOT_DEAD) break;
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > spin_limit) {                   // give up: flag the device, take no slot (the caller writes poison and ends)
+            if (f == RING_SLOT_DEAD || ++spins > spin_limit) {
+                // give up: flag the device, take no slot (the caller writes poison and ends), and leave the slot marked DEAD so
+                // that the generations queued behind this one give up at their first poll instead of spinning ~4 s each (a
+                // launch of 2^24 lanes has 64 generations per slot).  Should the late holder release after all, its store
+                // puts the slot back in service for whoever comes next.
                 if (lane == 0) {
                     u32* err = *reinterpret_cast<u32* const*>(state + RING_ERR_WORD);
                     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(state + flag_word, RING_SLOT_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return ring_table{nullptr};
             }
@@ -1192,7 +1233,7 @@ ZC_KERNEL void k_ris_eq(const u64* p, const u64* q, uint8_t* eq, size_t n)
     eq[i] = ris_eq(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)) ? 1 : 0;  // plain coordinates: both sides carry 1/R
 }
 // fused config-4 path: 32 B in -> registers -> 32 B out; the point never touches HBM
-ZC_KERNEL_2W void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, const u32* idx, size_t n)
+ZC_KERNEL_2W void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* out, uint8_t* ok, size_t n)
 {
     __shared__ u32 sk[9 * ZC_BLOCK];
     __shared__ u32 skey[ZC_BLOCK];
@@ -1201,21 +1242,18 @@ ZC_KERNEL_2W void k_ris_roundtrip_mul(const uint8_t* in, const u64* k, uint8_t* 
     const int tid = threadIdx.x;
     const size_t i = gid();
     const bool valid = i < n;
-    const size_t own = valid ? (idx ? (size_t)idx[i] : i) : 0;
+    const size_t own = valid ? i : 0;
     u64 w[4], l[5];
     load_scalar(l, k + 5 * own);
     int nbits;
     scalar_to_words(sk + tid, ZC_BLOCK, l, nbits);
     if (!valid) nbits = 0;
-    int e = tid;
-    if (!idx) {
-        snb[tid] = nbits;
-        e = block_cost_rank(skey, sperm, valid ? scalar_cost(l) : 0);
-        nbits = snb[e];
-    }
+    snb[tid] = nbits;
+    const int e = block_cost_rank(skey, sperm, valid ? scalar_cost(l) : 0);
+    nbits = snb[e];
     const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
-    const bool run = idx ? valid : (base + e < n);
-    const size_t ii = idx ? own : (run ? base + e : 0);
+    const bool run = base + e < n;
+    const size_t ii = run ? base + e : 0;
     load_words256(w, in + 32 * ii);
     pt P;
     const bool dec = ris_decompress(P, w);

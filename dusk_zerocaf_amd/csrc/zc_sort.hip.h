@@ -47,6 +47,7 @@ struct msm_sort_pass {
     u32 last;     // 1: the pass that takes the top bits (bin = d >> shift, zero digits -> bin 2^bits)
     u32 c;        // window width
     u32 idx_bits; // PACKED records: bits of the point index field
+    u32 w0;       // the table's first window (a sort over a GROUP of windows: W of them from w0 on, positions relative to the group's start)
 };
 
 ZC_DI u32 msm_sort_bins(const msm_sort_pass& p) { return (1u << p.bits) + p.last; }
@@ -345,14 +346,14 @@ ZC_DI void msm_sort_scatter_body(const u32* __restrict__ in, void* __restrict__ 
                 if (rank == 0) cnt[wv][bin] = pos + __popcll(peers);
                 if (IN == SORT_PACKED) {                        // (only ever the last pass) rebuild the digit, emit the final pair
                     const u32 idx = key[r] & ((1u << p.idx_bits) - 1);
-                    const u32 k = bin >> p.bits ? MSM_SORT_NONE : (w << (p.c - 1)) | (bin << p.shift) | b1[r];
+                    const u32 k = bin >> p.bits ? MSM_SORT_NONE : ((w + p.w0) << (p.c - 1)) | (bin << p.shift) | b1[r];
                     reinterpret_cast<uint2*>(stage)[pos] = make_uint2(k, idx | (key[r] & 0x80000000u));
                 } else if (OUT == SORT_PACKED) {                // pass 1 of two: drop the low bits, keep sign | high bits | index
                     const u32 d = key[r] & 0x7FFFFFFFu;
                     reinterpret_cast<u32*>(stage)[pos] = (key[r] & 0x80000000u) | ((d >> p.bits) << p.idx_bits) | val[r];
                     sbin[pos] = (unsigned short)bin;
                 } else if (p.last) {
-                    const u32 k = bin >> p.bits ? MSM_SORT_NONE : (w << (p.c - 1)) | (key[r] & 0x7FFFFFFFu);
+                    const u32 k = bin >> p.bits ? MSM_SORT_NONE : ((w + p.w0) << (p.c - 1)) | (key[r] & 0x7FFFFFFFu);
                     reinterpret_cast<uint2*>(stage)[pos] = make_uint2(k, val[r] | (key[r] & 0x80000000u));
                 } else {
                     reinterpret_cast<uint2*>(stage)[pos] = make_uint2(key[r], val[r]);

@@ -45,41 +45,39 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 constexpr int MAX_ARGS = 6;
 
 // Tuning knobs.  Read from the environment ONCE, when a context is created, and kept
-// with the context: a process can hold contexts with different settings side by side (which is how the GPU test
-// tier runs every selectable kernel path against the oracle), and no call path touches getenv afterwards.
-// 0 / -1 = "not set": the library's own choice applies.
+// with the context: a process can hold contexts with different settings side by side, and no call path touches
+// getenv afterwards.  0 / -1 = "not set": the library's own choice applies.
+//   * the first block is what a caller may have a reason to choose; every build reads it;
+//   * the second block are PATH FORCERS of the GPU test tier, read only by libzerocaf_hip_test.so (-DZC_TEST_HOOKS): they select,
+//     at test sizes, the paths the product takes at other sizes (two-word sort records and 8192-key tiles of shards beyond
+//     2^22 pairs, the in-line normalisation of shards beyond 2^23, run and segment lengths of other list lengths);
+//   * variants that were measured and lost (chains in line, one lane per fold addition, packed 96-byte records, other
+//     launch sizes ...) are compile-time macros below: `python -m dusk_zerocaf_amd.build --variant NAME MACRO=V` builds an
+//     A/B library, the product never carries the switch.
 struct Tuning {
     long host_chunks = 0;            // ZC_HOST_CHUNKS=k: host batches move in k chunks
-    bool balance_global = false;     // ZC_BALANCE=global: batch-wide cost-sorted permutation for the block-shaped strict kernels
     bool sched_block = false;        // ZC_SCHED=block: one workgroup per 256 elements instead of persistent waves
     unsigned ring_slots = 0;         // ZC_RING_SLOTS=k (1..512): wave slots per XCD of the windowed core's table ring
     bool ristretto_strict = false;   // ZC_RISTRETTO_STRICT=1: config-4 round trip on the reference's formula sequence
     long inv_chunk = 0;              // ZC_INV_CHUNK=c (1..64): elements per lane sharing one inversion
     int jacobi_rounds = -1;          // ZC_JACOBI_ROUNDS=r (0..200): rounds before legendre_symbol falls back to the power
     int msm_window = 0;              // ZC_MSM_WINDOW=c
+    int msm_affine = -1;             // ZC_MSM_AFFINE=0/1: projective 128-byte records / affine 96-byte records whatever the shard size
+    int msm_groups[4] = {0, 0, 0, 0};   // ZC_MSM_GROUPS="a,b[,c[,d]]": windows per group, top group first ("1" = one group)
+    int msm_ngroups = 0;
+    // ---- test-hooks build only
     int msm_sort_packed = -1;        // ZC_MSM_SORT_PACKED=0/1
     int msm_sort_big = -1;           // ZC_MSM_SORT_BIG=0/1
     long msm_sort_g = 0;             // ZC_MSM_SORT_G=g (1..64)
-    int msm_affine = -1;             // ZC_MSM_AFFINE=0/1
     int msm_run = 0;                 // ZC_MSM_RUN=T (4..4096)
     int msm_run_edges = 0;           // ZC_MSM_RUN_EDGES=T (4..4096, even)
     int msm_fork = -1;               // ZC_MSM_FORK=0/1
     int msm_affine_chunk = 0;        // ZC_MSM_AFFINE_CHUNK=c (1..64)
     int msm_seg = 0;                 // ZC_MSM_SEG=s (power of two, 2..256)
-    int msm_groups[4] = {0, 0, 0, 0};   // ZC_MSM_GROUPS="a,b[,c[,d]]": windows per group, top group first ("1" = one group)
-    int msm_ngroups = 0;
-    int msm_tail_prio = -1;          // ZC_MSM_TAIL_PRIO=0/1: the groups' tails on high-priority streams (default 1)
-    long msm_seg_quad = -1;          // ZC_MSM_SEG_QUAD=s: four lanes per segment in launches of at most s segments (0: never)
-    long msm_group_lanes = 0;        // ZC_MSM_GROUP_LANES=l: lanes a window group's bucket-sum launch keeps busy (log2, 15..22)
-    int msm_rec_stride = 0;          // ZC_MSM_REC_STRIDE=96/128: stride of the affine records (128: one record per cache line)
-    int msm_tail_side = -1;          // ZC_MSM_TAIL_SIDE=0: the groups' chains on the caller's stream, one after the other (A/B: no overlap)
-    int msm_fold_quad = -1;          // ZC_MSM_FOLD_QUAD=0/1: the fold tree with four lanes per addition (default 1)
-    long msm_group_wgs = -1;         // ZC_MSM_GROUP_WGS=k: workgroups per CU of the bucket-sum launches that run beside a tail (0: no limit)
-#ifdef ZC_TEST_HOOKS
     bool test_ring_poison = false;   // ZC_TEST_RING_POISON: pretend a wave of every windowed-core launch gave up
     unsigned test_ring_spins = 0;    // ZC_TEST_RING_SPINS=b: waves give up after 2^b polls (default 22, about 4 s)
-#endif
 };
+// (the compile-time variants of the MSM pipeline: zc_msm.hip.h, ZC_MSM_* macros)
 inline long env_long(const char* name, long lo, long hi, long unset)
 {
     const char* e = getenv(name);
@@ -91,25 +89,13 @@ Tuning tuning_from_env()
 {
     Tuning t;
     t.host_chunks = env_long("ZC_HOST_CHUNKS", 1, 1 << 20, 0);
-    if (const char* e = getenv("ZC_BALANCE")) t.balance_global = std::string(e) == "global";
     if (const char* e = getenv("ZC_SCHED")) t.sched_block = std::string(e) == "block";
     t.ring_slots = (unsigned)env_long("ZC_RING_SLOTS", 1, 512, 0);
     t.ristretto_strict = env_long("ZC_RISTRETTO_STRICT", 0, 1 << 30, 0) != 0;
     t.inv_chunk = env_long("ZC_INV_CHUNK", 1, 64, 0);
     t.jacobi_rounds = (int)env_long("ZC_JACOBI_ROUNDS", 0, 200, -1);
     t.msm_window = (int)env_long("ZC_MSM_WINDOW", 1, 64, 0);
-    t.msm_sort_packed = (int)env_long("ZC_MSM_SORT_PACKED", 0, 1 << 30, -1);
-    t.msm_sort_big = (int)env_long("ZC_MSM_SORT_BIG", 0, 1 << 30, -1);
-    t.msm_sort_g = env_long("ZC_MSM_SORT_G", 1, 64, 0);
     t.msm_affine = (int)env_long("ZC_MSM_AFFINE", 0, 1 << 30, -1);
-    t.msm_run = (int)env_long("ZC_MSM_RUN", 4, 4096, 0);
-    t.msm_run_edges = (int)env_long("ZC_MSM_RUN_EDGES", 4, 4096, 0);
-    t.msm_fork = (int)env_long("ZC_MSM_FORK", 0, 1 << 30, -1);
-    t.msm_affine_chunk = (int)env_long("ZC_MSM_AFFINE_CHUNK", 1, 64, 0);
-    {
-        const long f = env_long("ZC_MSM_SEG", 2, 256, 0);
-        if (f && (f & (f - 1)) == 0) t.msm_seg = (int)f;
-    }
     if (const char* e = getenv("ZC_MSM_GROUPS")) {
         for (const char* q = e; *q && t.msm_ngroups < 4;) {
             char* end = nullptr;
@@ -120,17 +106,18 @@ Tuning tuning_from_env()
             q = end + 1;
         }
     }
-    t.msm_tail_prio = (int)env_long("ZC_MSM_TAIL_PRIO", 0, 1, -1);
-    t.msm_seg_quad = env_long("ZC_MSM_SEG_QUAD", 0, 1 << 24, -1);
-    t.msm_group_lanes = env_long("ZC_MSM_GROUP_LANES", 15, 22, 0);
-    t.msm_group_wgs = env_long("ZC_MSM_GROUP_WGS", 0, 8, -1);
-    t.msm_fold_quad = (int)env_long("ZC_MSM_FOLD_QUAD", 0, 1, -1);
-    t.msm_tail_side = (int)env_long("ZC_MSM_TAIL_SIDE", 0, 1, -1);
-    {
-        const long v = env_long("ZC_MSM_REC_STRIDE", 96, 128, 0);
-        if (v == 96 || v == 128) t.msm_rec_stride = (int)v;
-    }
 #ifdef ZC_TEST_HOOKS
+    t.msm_sort_packed = (int)env_long("ZC_MSM_SORT_PACKED", 0, 1 << 30, -1);
+    t.msm_sort_big = (int)env_long("ZC_MSM_SORT_BIG", 0, 1 << 30, -1);
+    t.msm_sort_g = env_long("ZC_MSM_SORT_G", 1, 64, 0);
+    t.msm_run = (int)env_long("ZC_MSM_RUN", 4, 4096, 0);
+    t.msm_run_edges = (int)env_long("ZC_MSM_RUN_EDGES", 4, 4096, 0);
+    t.msm_fork = (int)env_long("ZC_MSM_FORK", 0, 1 << 30, -1);
+    t.msm_affine_chunk = (int)env_long("ZC_MSM_AFFINE_CHUNK", 1, 64, 0);
+    {
+        const long f = env_long("ZC_MSM_SEG", 2, 256, 0);
+        if (f && (f & (f - 1)) == 0) t.msm_seg = (int)f;
+    }
     t.test_ring_poison = getenv("ZC_TEST_RING_POISON") != nullptr;
     t.test_ring_spins = (unsigned)env_long("ZC_TEST_RING_SPINS", 1, 30, 0);
 #endif
@@ -172,6 +159,7 @@ struct DevState {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t grp = nullptr;          // MSM window groups: the chains of the groups above the lowest one, one after the other (highest priority)
     hipEvent_t ev_grp_go[3] = {}, ev_grp_done[3] = {};   // group g's bucket sums are enqueued / its chain is through
+    hipEvent_t ev_digits = nullptr, ev_sorted[4] = {};   // the digit words are written / group g's keys are sorted (groups sorted on their own)
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -417,34 +405,37 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // 256 MB Infinity Cache (zc_kernels.hip.h, "LDS-staged element I/O").
 constexpr size_t STREAM_BYTES = (size_t)256 << 20;
 
-int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt)
+// `stream_min`: the call's bytes from which the staged kernel wins (STREAM_BYTES for the 40-byte element ops; the point ops
+// -- 160-byte records, far beyond what a lane reads well on its own -- from the first full launch on).
+int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt, size_t stream_min = STREAM_BYTES)
 {
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     // elt == 0: (point, scalar) -> point
     Arg args[3] = {in_arg(a, elt ? elt : 160), in_arg(b, elt ? elt : 40), out_arg(out, elt ? elt : 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        const bool stream = k_stream && cnt * elt * 3 > STREAM_BYTES && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
+        const bool stream = k_stream && cnt * elt * 3 > stream_min && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
         hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
     }, elt == 0);
 }
-int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt)
+int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt, kun_t k_stream = nullptr, size_t stream_min = STREAM_BYTES)
 {
     REQUIRE(a); REQUIRE(out);
     Arg args[2] = {in_arg(a, elt), out_arg(out, elt)};
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
-        hipLaunchKernelGGL(k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
+        const bool stream = k_stream && cnt * elt * 2 > stream_min && aligned16(d[0]) && aligned16(d[1]);
+        hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
 }
 
 // Cost-sorted permutation for the unified-step kernels (see zc_kernels.hip.h "lane balancing").
 // Returns nullptr (natural order) for small batches or when scratch cannot be had.
-// ZC_BALANCE=global selects it; the default is the in-kernel block-local ranking, which keeps
-// HBM traffic algorithmic (a batch-wide permutation turns record reads into cache-line gathers).
+// The persistent-wave kernel walks it; the block-shaped kernels (small batches, ZC_SCHED=block) rank their 256 scalars in
+// LDS instead, which keeps HBM traffic algorithmic.
 constexpr size_t BALANCE_MIN_N = 1 << 14;
 constexpr size_t BAL_COUNTERS = 64;                       // u32 work counters of the persistent kernels, after the bins
-const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt, bool force = false, zc::u32** counter = nullptr)
+const zc::u32* balance_index(DevState& D, const u64* k, size_t cnt, zc::u32** counter)
 {
-    if ((!force && !D.tune.balance_global) || cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
+    if (cnt < BALANCE_MIN_N || cnt > 0xFFFFFFFFull) return nullptr;
     const size_t need = (zc::ZC_COST_BINS + BAL_COUNTERS + cnt) * sizeof(zc::u32);
     if (ensure(&D.bal, &D.bal_bytes, need) != ZC_OK) return nullptr;
     zc::u32* hist = (zc::u32*)D.bal;
@@ -466,7 +457,7 @@ constexpr size_t PW_MIN_ELEMS = (size_t)1 << 17;
 // default kernel is faster again).
 constexpr unsigned SMALL_LAUNCH_BLOCKS = 256;
 constexpr size_t QUAD_LAUNCH_ELEMS = (size_t)1 << 14;     // 4 lanes per element still leave one wave per SIMD
-typedef void (*strict_kernel_t)(const u64*, const u64*, size_t, u64*, const zc::u32*, size_t);
+typedef void (*strict_kernel_t)(const u64*, const u64*, size_t, u64*, size_t);
 inline strict_kernel_t strict_kernel_for(size_t cnt)
 {
     return grid_for(cnt) <= SMALL_LAUNCH_BLOCKS ? zc::k_ed_scalar_mul_small : zc::k_ed_scalar_mul;
@@ -488,17 +479,27 @@ int fast_ring(DevState& D, size_t cnt, L&& launch)
         // address parked behind the ring state): the host reads it at every entry point without any synchronisation.
         if (!D.ring_err) {
             void* h = nullptr;
-            hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+            // coherent (fine-grained) so that the host sees the store while kernels run whatever HIP_HOST_COHERENT says;
+            // portable so that every device slot of a multi-device context may map it
+            hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
             if (e != hipSuccess) return fail(ZC_ERR_NOMEM, "hipHostMalloc(ring error word)", e);
             D.ring_err = (volatile zc::u32*)h;
             *D.ring_err = 0;
         }
-        rc = ensure(&D.ring, &D.ring_bytes, zc::RING_ALLOC_WORDS * sizeof(zc::u32));
-        if (rc) return rc;
+        // the ring state is published (D.ring) only once the error word's address sits behind it: a failure on the way
+        // leaves D.ring null and the next call starts over -- a wave never reads an unset address
+        void* ring = nullptr;
+        HIP_TRY(hipMalloc(&ring, zc::RING_ALLOC_WORDS * sizeof(zc::u32)));
         void* dev_view = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&dev_view, (void*)D.ring_err, 0));
+        hipError_t e = hipHostGetDevicePointer(&dev_view, (void*)D.ring_err, 0);
         const u64 addr = (u64)(uintptr_t)dev_view;
-        HIP_TRY(hipMemcpy((zc::u32*)D.ring + zc::RING_ERR_WORD, &addr, sizeof addr, hipMemcpyHostToDevice));   // once per device slot
+        if (e == hipSuccess) e = hipMemcpy((zc::u32*)ring + zc::RING_ERR_WORD, &addr, sizeof addr, hipMemcpyHostToDevice);   // once per device slot
+        if (e != hipSuccess) {
+            (void)hipFree(ring);
+            return fail(ZC_ERR_HIP, "windowed core: ring state setup", e);
+        }
+        D.ring = ring;
+        D.ring_bytes = zc::RING_ALLOC_WORDS * sizeof(zc::u32);
     }
     // a launch hands out fewer than 2^19 generations of its slots (the 19-bit field of the word ring_acquire parks)
     const zc::u32 slots = D.tune.ring_slots ? (zc::u32)D.tune.ring_slots : zc::RING_SLOTS;
@@ -534,21 +535,20 @@ int scalar_mul_impl(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t*
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
         if (cnt >= PW_MIN_ELEMS && !D.tune.sched_block) {
             zc::u32* counter = nullptr;
-            if (const zc::u32* perm = balance_index(D, (const u64*)d[1], cnt, true, &counter)) {
+            if (const zc::u32* perm = balance_index(D, (const u64*)d[1], cnt, &counter)) {
                 hipLaunchKernelGGL(zc::k_ed_scalar_mul_pw, dim3((unsigned)(3 * D.cus)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1],
                                    (u64*)d[2], perm, counter, (zc::u32)cnt);
                 return;
             }
         }
-        const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
-        if (cnt <= QUAD_LAUNCH_ELEMS && !idx) {
+        if (cnt <= QUAD_LAUNCH_ELEMS) {
             // four lanes per element: the batch cannot fill the chip anyway, so buy latency with lanes
             hipLaunchKernelGGL(zc::k_ed_scalar_mul_quad, dim3((unsigned)((cnt + 63) / 64)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0],
                                (const u64*)d[1], (u64*)d[2], cnt);
             return;
         }
         hipLaunchKernelGGL(strict_kernel_for(cnt), dim3(grid_for(cnt)),
-                           dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (size_t)5, (u64*)d[2], idx, cnt);
+                           dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (size_t)5, (u64*)d[2], cnt);
     }, true);
 }
 // the same scalar for every point, handed to the kernel by value
@@ -649,42 +649,58 @@ MsmSortPlan msm_sort_plan(size_t n, int c, int W, const Tuning& tune)
         p.last = i + 1 == pl.passes ? 1u : 0u;
         p.c = (zc::u32)c;
         p.idx_bits = pl.packed ? (zc::u32)idx_bits : 0;
+        p.w0 = 0;
         shift += bits;
         const size_t words = ((size_t)W * ((size_t)1 << bits) + (p.last ? (size_t)W : 0)) * ncols;
         pl.table_words = std::max(pl.table_words, (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS);
     }
     return pl;
 }
-// digits (window-major words in `digits`) -> pairs ordered by bucket in *sorted (buf_a or buf_b).  buf_b holds m
-// pairs, or m words when the plan is packed; `tables` = two tables of pl.table_words words.
-int msm_sort(DevState& D, const MsmSortPlan& pl, const zc::u32* digits, uint2* buf_a, void* buf_b, zc::u32* tables, zc::u32* sums, const uint2** sorted)
+// table words of one pass over `nw` windows, padded to whole scan blocks
+inline size_t msm_sort_table_words(const zc::msm_sort_pass& p, size_t nw)
 {
-    const zc::u32* in = digits;
+    const size_t words = (nw * ((size_t)1 << p.bits) + (p.last ? nw : 0)) * p.ncols;
+    return (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS;
+}
+// Sorts the windows [w0, w0 + nw) of the window-major digit words on stream `st`: pairs ordered by bucket in buf_a, in the
+// windows' own part of the arrays ([w0 n, (w0 + nw) n): buckets first, the zero digits of these windows behind them).  With
+// w0 = 0, nw = W that is the whole list with every zero digit at its end; a pipeline that takes the windows in groups sorts
+// every group on its own, so that the bucket sums of the top group need not wait for the keys of the others.
+// buf_b holds m pairs, or m words when the plan is packed; `tables` = two tables of `table_words` words (this call's own);
+// the last pass's scanned table stays in tables + ((passes - 1) & 1) * table_words (positions relative to w0 n).
+int msm_sort(DevState& D, hipStream_t st, const MsmSortPlan& pl, int w0, int nw, const zc::u32* digits, uint2* buf_a, void* buf_b, zc::u32* tables, size_t table_words,
+             zc::u32* sums)
+{
+    const size_t base = (size_t)w0 * pl.pass[0].n;            // the group's first entry in every array
+    const zc::u32* in = digits + base;
+    uint2* a = buf_a + base;
+    void* b = !buf_b ? nullptr : pl.packed ? (void*)((zc::u32*)buf_b + base) : (void*)((uint2*)buf_b + base);
     // the last pass writes buf_a; the passes before it alternate so that no pass reads what it writes
-    void* out = (pl.passes & 1) ? (void*)buf_a : buf_b;
+    void* out = (pl.passes & 1) ? (void*)a : b;
     for (int i = 0; i < pl.passes; i++) {
-        const zc::msm_sort_pass& p = pl.pass[i];
-        zc::u32* table = tables + (size_t)(i & 1) * pl.table_words;
+        zc::msm_sort_pass p = pl.pass[i];
+        p.W = (zc::u32)nw;
+        p.w0 = (zc::u32)w0;
+        zc::u32* table = tables + (size_t)(i & 1) * table_words;
         const size_t words = ((size_t)p.W * ((size_t)1 << p.bits) + (p.last ? (size_t)p.W : 0)) * p.ncols;
-        const size_t padded = (words + zc::SCAN_BLOCK_ELEMS - 1) / zc::SCAN_BLOCK_ELEMS * zc::SCAN_BLOCK_ELEMS;
+        const size_t padded = msm_sort_table_words(p, (size_t)nw);
         const unsigned nblk = (unsigned)(padded / zc::SCAN_BLOCK_ELEMS), grid = (unsigned)(p.W * p.ncols);
-        if (padded > words) HIP_TRY(hipMemsetAsync(table + words, 0, (padded - words) * sizeof(zc::u32), D.s()));
-        hipLaunchKernelGGL(!i ? zc::k_msm_sort_hist : pl.packed ? zc::k_msm_sort_hist_packed : zc::k_msm_sort_hist_pairs, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, table, p);
-        hipLaunchKernelGGL(zc::k_scan_reduce, dim3(nblk), dim3(zc::ZC_BLOCK), 0, D.s(), (const zc::u32*)table, sums);
-        hipLaunchKernelGGL(zc::k_scan_sums, dim3(1), dim3(zc::ZC_BLOCK), 0, D.s(), sums, (zc::u32)nblk);
-        hipLaunchKernelGGL(zc::k_scan_apply, dim3(nblk), dim3(zc::ZC_BLOCK), 0, D.s(), table, (const zc::u32*)sums);
+        if (padded > words) HIP_TRY(hipMemsetAsync(table + words, 0, (padded - words) * sizeof(zc::u32), st));
+        hipLaunchKernelGGL(!i ? zc::k_msm_sort_hist : pl.packed ? zc::k_msm_sort_hist_packed : zc::k_msm_sort_hist_pairs, dim3(grid), dim3(zc::ZC_BLOCK), 0, st, in, table, p);
+        hipLaunchKernelGGL(zc::k_scan_reduce, dim3(nblk), dim3(zc::ZC_BLOCK), 0, st, (const zc::u32*)table, sums);
+        hipLaunchKernelGGL(zc::k_scan_sums, dim3(1), dim3(zc::ZC_BLOCK), 0, st, sums, (zc::u32)nblk);
+        hipLaunchKernelGGL(zc::k_scan_apply, dim3(nblk), dim3(zc::ZC_BLOCK), 0, st, table, (const zc::u32*)sums);
         if (pl.packed && i == 0)
-            hipLaunchKernelGGL(zc::k_msm_sort_scatter_pack, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, (zc::u32*)out, (const zc::u32*)table, p);
+            hipLaunchKernelGGL(zc::k_msm_sort_scatter_pack, dim3(grid), dim3(zc::ZC_BLOCK), 0, st, in, (zc::u32*)out, (const zc::u32*)table, p);
         else if (pl.packed)
-            hipLaunchKernelGGL(zc::k_msm_sort_scatter_unpack, dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, (uint2*)out, (const zc::u32*)table,
-                               (const zc::u32*)(tables + (size_t)((i - 1) & 1) * pl.table_words), p);
+            hipLaunchKernelGGL(zc::k_msm_sort_scatter_unpack, dim3(grid), dim3(zc::ZC_BLOCK), 0, st, in, (uint2*)out, (const zc::u32*)table,
+                               (const zc::u32*)(tables + (size_t)((i - 1) & 1) * table_words), p);
         else
             hipLaunchKernelGGL(pl.big ? (i ? zc::k_msm_sort_scatter_pairs_big : zc::k_msm_sort_scatter_big) : (i ? zc::k_msm_sort_scatter_pairs : zc::k_msm_sort_scatter),
-                               dim3(grid), dim3(zc::ZC_BLOCK), 0, D.s(), in, (uint2*)out, (const zc::u32*)table, p);
+                               dim3(grid), dim3(zc::ZC_BLOCK), 0, st, in, (uint2*)out, (const zc::u32*)table, p);
         in = reinterpret_cast<const zc::u32*>(out);
-        out = out == (void*)buf_a ? buf_b : (void*)buf_a;
+        out = out == (void*)a ? b : (void*)a;
     }
-    *sorted = buf_a;
     return ZC_OK;
 }
 
@@ -709,6 +725,7 @@ struct MsmPlan {
     int rec_bytes = 128;           // stride of the cached records (affine: 96 packed or 128 = one per cache line; projective: 128)
     int G = 1;                     // window groups, top windows first: gw[g] windows, run length gT[g]
     int gw[4] = {0, 0, 0, 0}, gT[4] = {0, 0, 0, 0};
+    int bad_groups = 0;            // ZC_MSM_GROUPS was given and adds up to this many windows instead of W: the call fails
     MsmSortPlan sort;
 };
 // Run length of the bucket-sum kernel for a list of m entries: 128 entries per lane, fewer when the list is short (keep
@@ -738,7 +755,7 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     // affine records: 96 bytes of payload at a 128-byte stride -- one record per cache line.  Packed (96-byte stride) three records
     // of four straddle two lines: measured (rocprofv3 TCC_EA0_RDREQ of k_msm_runs_affine, profiles/r04_msm_record_stride.md)
     // 34.6 -> 25.1 read requests per pair at 2^21 pairs, 34.3 -> 27.7 at 2^24; 2^21: 3.50 -> 3.50 ms, 2^22: 6.30 -> 6.13, 2^24: 21.18 -> 20.22.
-    p.rec_bytes = p.affine ? (tune.msm_rec_stride ? tune.msm_rec_stride : 128) : 128;
+    p.rec_bytes = p.affine ? ZC_MSM_REC_STRIDE : 128;
     p.T = msm_run_length(p.m, tune);
     p.TE = 8;                                             // deeper levels: short lists, short runs (even: see k_msm_runs_edges)
     if (tune.msm_run_edges) p.TE = tune.msm_run_edges & ~1;
@@ -751,6 +768,8 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
         if (tune.msm_ngroups >= 2 && sum == p.W) {
             p.G = tune.msm_ngroups;
             for (int g = 0; g < p.G; g++) p.gw[g] = tune.msm_groups[g];
+        } else if (tune.msm_ngroups >= 2) {
+            p.bad_groups = sum;                           // fail closed: a split for another window count is not silently replaced by one group
         } else if (tune.msm_ngroups == 0 && p.W >= 8 && cnt >= ((size_t)1 << 21) && cnt < ((size_t)1 << 22)) {
             // default for config-5-sized shards (2^21 pairs: 16 windows as 9 + 4 + 3): three groups, the lowest (exposed) one the
             // smallest.  Measured on one box, 2^21 pairs (tools/msm_groups_sweep.py): one group 3.68 ms, 13+3 3.50, 12+4 3.51,
@@ -765,7 +784,7 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     // a group's launch keeps 2^17 lanes busy like the whole list (ZC_MSM_GROUP_LANES=16 / 17 / 18 / 19 at 2^21 pairs in three groups:
     // 3.71 / 3.48 / 3.61 / 4.30 ms: shorter runs cut more buckets, and every cut is an edge for the levels behind)
     for (int g = 0; g < p.G; g++)
-        p.gT[g] = p.G == 1 ? p.T : msm_run_length(cnt * (size_t)p.gw[g], tune, tune.msm_group_lanes ? (int)tune.msm_group_lanes : 17);
+        p.gT[g] = p.G == 1 ? p.T : msm_run_length(cnt * (size_t)p.gw[g], tune, ZC_MSM_GROUP_LANES);
     return p;
 }
 
@@ -779,8 +798,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         if (rc) return rc;
         rc = ensure(&D.tmp[1], &D.tmp_bytes[1], ((cnt + 1) / 2) * 160 + 256);
         if (rc) return rc;
-        hipLaunchKernelGGL(strict_kernel_for(cnt), dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, dK, (size_t)5, (u64*)D.tmp[0],
-                           (const zc::u32*)nullptr, cnt);
+        hipLaunchKernelGGL(strict_kernel_for(cnt), dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dP, dK, (size_t)5, (u64*)D.tmp[0], cnt);
         *result = fold_all(D, (u64*)D.tmp[0], (u64*)D.tmp[1], cnt);
         HIP_TRY(hipGetLastError());
         return ZC_OK;
@@ -788,6 +806,11 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
     if (cnt > 0x7FFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 31-bit point indices");
     const Tuning& tune = D.tune;
     const MsmPlan mp = msm_plan(cnt, aligned16(dP), tune);
+    if (mp.bad_groups) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "zc_msm: ZC_MSM_GROUPS adds up to %d windows, a shard of %zu pairs has %d (%d-bit windows)", mp.bad_groups, cnt, mp.W, mp.c);
+        return fail(ZC_ERR_BAD_ARG, msg);
+    }
     const int c = mp.c, W = mp.W, seg = mp.seg, TE = mp.TE;
     const size_t m = mp.m, nb = mp.nb, nseg = mp.nseg;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
@@ -833,8 +856,17 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         zc::u32* digits = cv.take<zc::u32>(m);
         uint2* pairs_a = cv.take<uint2>(m);
         void* pairs_b = plan.passes == 1 ? nullptr : plan.packed ? (void*)cv.take<zc::u32>(m) : (void*)cv.take<uint2>(m);
-        zc::u32* sort_table = cv.take<zc::u32>(2 * plan.table_words);
-        zc::u32* sort_sums = cv.take<zc::u32>(plan.table_words / zc::SCAN_BLOCK_ELEMS + 1);
+        // one sort for all windows, or -- window groups -- one per group (its own tables: the bucket sums read a group's last scan table)
+        const bool sort_per_group = G > 1 && ZC_MSM_SORT_PER_GROUP != 0;
+        zc::u32* sort_table[4] = {};
+        zc::u32* sort_sums[4] = {};
+        size_t sort_table_words[4] = {};
+        for (int g = 0; g < (sort_per_group ? G : 1); g++) {
+            const size_t nw = sort_per_group ? (size_t)grp[g].nw : (size_t)W;
+            for (int i = 0; i < plan.passes; i++) sort_table_words[g] = std::max(sort_table_words[g], msm_sort_table_words(plan.pass[i], nw));
+            sort_table[g] = cv.take<zc::u32>(2 * sort_table_words[g]);
+            sort_sums[g] = cv.take<zc::u32>(sort_table_words[g] / zc::SCAN_BLOCK_ELEMS + 1);
+        }
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
         uint8_t* present = cv.take<uint8_t>(nb);
@@ -872,28 +904,44 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         }
         if (ps != D.s()) HIP_TRY(hipEventRecord(D.ev_join, ps));
         hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, digits, cnt, c, W);
-        const uint2* sorted = nullptr;
-        {
-            int rc = msm_sort(D, plan, digits, pairs_a, pairs_b, sort_table, sort_sums, &sorted);
-            if (rc) return rc;
+        const uint2* sorted = pairs_a;
+        // The key sort.  With window groups every group is sorted on its own, top group first: its bucket sums start as soon as
+        // ITS keys are in order (and the points are normalised), and the sorts of the groups below -- memory- and LDS-bound --
+        // run under those bucket sums -- multiplier-bound -- on the side stream the normalisation has just left.
+        HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
+        hipStream_t side = ps != D.s() ? ps : D.s();            // behind the normalisation (the low-priority stream), or in line
+        if (sort_per_group) {
+            if (side != D.s()) {
+                HIP_TRY(hipEventRecord(D.ev_digits, D.s()));
+                HIP_TRY(hipStreamWaitEvent(side, D.ev_digits, 0));
+            }
+            // the top group's keys now; the others are enqueued behind the top group's bucket-sum launch (below): the host
+            // enqueues a hundred small launches per call, and what the chip needs first has to be enqueued first
+            if (int rc = msm_sort(D, D.s(), plan, grp[0].w0, grp[0].nw, digits, pairs_a, pairs_b, sort_table[0], sort_table_words[0], sort_sums[0])) return rc;
+        } else {
+            if (int rc = msm_sort(D, D.s(), plan, 0, W, digits, pairs_a, pairs_b, sort_table[0], sort_table_words[0], sort_sums[0])) return rc;
         }
         if (ps != D.s()) HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_join, 0));
-        HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
         // where window w's part of the sorted list starts: the last pass's scanned table at (window w, bin 0, column 0); the row
-        // behind the last window is the zero digits' = the end of the buckets (zc_sort.hip.h: msm_sort_slot)
+        // behind the last window is the zero digits' = the end of the buckets (zc_sort.hip.h: msm_sort_slot).  A group sorted on
+        // its own counts from the start of its own part of the list.
         const zc::msm_sort_pass& lastp = plan.pass[plan.passes - 1];
-        const zc::u32* last_table = sort_table + (size_t)((plan.passes - 1) & 1) * plan.table_words;
-        auto window_start = [&](int w) { return last_table + ((size_t)w << lastp.bits) * lastp.ncols; };
+        auto window_start = [&](int g, int w) {
+            const int ti = sort_per_group ? g : 0;
+            const zc::u32* last_table = sort_table[ti] + (size_t)((plan.passes - 1) & 1) * sort_table_words[ti];
+            return last_table + ((size_t)(sort_per_group ? w - grp[g].w0 : w) << lastp.bits) * lastp.ncols;
+        };
         for (int g = 0; g < G; g++) {
             Group& gr = grp[g];
+            if (sort_per_group && g > 0 && ps != D.s()) HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_sorted[g], 0));
             const size_t b0 = (size_t)gr.w0 << (c - 1);                  // the group's first bucket
             const size_t nsegg = (size_t)gr.nw * spw;
             // A launch that runs beside the chain of the group above it leaves that chain room: its workgroups are padded with
             // dynamic LDS so that only `wgs` of them fit a CU (three: one wave slot per SIMD, 200 VGPRs and 39 KB of LDS stay free;
             // a chain kernel that finds every slot taken waits for a bucket-sum workgroup to retire).
             size_t pad = 0;
-            if (g > 0) {
-                const long wgs = tune.msm_group_wgs >= 0 ? tune.msm_group_wgs : 3;
+            if (g > 0 || sort_per_group) {                       // (the top group's launch runs beside the sorts of the groups below it)
+                const long wgs = ZC_MSM_GROUP_WGS;
                 const size_t own = (affine ? 6 : 8) * 16 * (size_t)zc::MSM_RUN_BLOCK;       // the kernel's static staging area
                 if (wgs > 0 && (size_t)(wgs + 1) * own <= 163840) {
                     const size_t per = 163840 / (size_t)(wgs + 1) + 512;                     // wgs + 1 of these do not fit 160 KB
@@ -902,9 +950,15 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             }
             hipLaunchKernelGGL(affine ? zc::k_msm_runs_affine : zc::k_msm_runs, dim3((unsigned)((gr.nl0 + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), pad,
                                D.s(), sorted, (const zc::u32*)cached, (zc::u32)m, (zc::u32)gr.T, (zc::u32)nb, buckets, present, ekeys[0], erecs[0],
-                               G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0), G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0 + gr.nw), (zc::u32)gr.nl0,
-                               (zc::u32)gr.slot0, rec_words);
-            hipStream_t st = tune.msm_tail_side == 0 ? D.s() : gr.st;
+                               G == 1 ? (const zc::u32*)nullptr : window_start(g, gr.w0), G == 1 ? (const zc::u32*)nullptr : window_start(g, gr.w0 + gr.nw),
+                               sort_per_group ? (zc::u32)((size_t)gr.w0 * cnt) : 0u, (zc::u32)gr.nl0, (zc::u32)gr.slot0, rec_words);
+            if (sort_per_group && g == 0) {
+                for (int h = 1; h < G; h++) {
+                    if (int rc = msm_sort(D, side, plan, grp[h].w0, grp[h].nw, digits, pairs_a, pairs_b, sort_table[h], sort_table_words[h], sort_sums[h])) return rc;
+                    if (side != D.s()) HIP_TRY(hipEventRecord(D.ev_sorted[h], side));
+                }
+            }
+            hipStream_t st = ZC_MSM_TAIL_SIDE ? gr.st : D.s();
             if (st != D.s()) {
                 HIP_TRY(hipEventRecord(D.ev_grp_go[g], D.s()));
                 HIP_TRY(hipStreamWaitEvent(st, D.ev_grp_go[g], 0));
@@ -936,7 +990,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             u64* cur = seg_out + 20 * (size_t)gr.w0 * spw;
             u64* nxt = fold_b + 20 * (size_t)gr.w0 * spw;
             // few segments (the lowest group, small shards): four lanes per segment, three multiplication latencies per addition
-            const size_t quad_max = tune.msm_seg_quad >= 0 ? (size_t)tune.msm_seg_quad : QUAD_LAUNCH_ELEMS;
+            const size_t quad_max = (size_t)ZC_MSM_SEG_QUAD;
             if (nsegg <= quad_max)
                 hipLaunchKernelGGL(zc::k_msm_segments_quad, dim3((unsigned)((nsegg + 63) / 64)), dim3(zc::ZC_BLOCK), 0, st, (const zc::u32*)(buckets + b0 * zc::MSM_RAW_WORDS),
                                    (const uint8_t*)(present + b0), cur, nsegg, c, seg);
@@ -946,17 +1000,20 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             // fold every window's segment sums (a power of two per window) to one point per window:
             // one workgroup per group of up to 128 points (four lanes per addition) or 512, two launches
             size_t left = nsegg;
-            const bool fold_quad = tune.msm_fold_quad != 0;      // ZC_MSM_FOLD_QUAD=0: one lane per addition, 512 points per workgroup
             while (left > (size_t)gr.nw) {
-                const size_t fg = std::min<size_t>(fold_quad ? 128 : 512, left / (size_t)gr.nw);
-                hipLaunchKernelGGL(fold_quad ? zc::k_msm_fold_groups_quad : zc::k_msm_fold_groups, dim3((unsigned)(left / fg)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)cur, nxt,
-                                   (zc::u32)fg);
+#if ZC_MSM_FOLD_QUAD
+                const size_t fg = std::min<size_t>(128, left / (size_t)gr.nw);
+                hipLaunchKernelGGL(zc::k_msm_fold_groups_quad, dim3((unsigned)(left / fg)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)cur, nxt, (zc::u32)fg);
+#else
+                const size_t fg = std::min<size_t>(512, left / (size_t)gr.nw);
+                hipLaunchKernelGGL(zc::k_msm_fold_groups, dim3((unsigned)(left / fg)), dim3(zc::ZC_BLOCK), 0, st, (const u64*)cur, nxt, (zc::u32)fg);
+#endif
                 left /= fg;
                 std::swap(cur, nxt);
             }
             // Horner's rule, top window first across the groups: this group continues from the result of the group above it
             // (same stream, or -- the lowest group -- behind that stream's event)
-            if (g == G - 1 && G > 1 && tune.msm_tail_side != 0) HIP_TRY(hipStreamWaitEvent(st, D.ev_grp_done[G - 2], 0));
+            if (g == G - 1 && G > 1 && ZC_MSM_TAIL_SIDE) HIP_TRY(hipStreamWaitEvent(st, D.ev_grp_done[G - 2], 0));
             hipLaunchKernelGGL(zc::k_msm_window_combine, dim3(1), dim3(64), 0, st, (const u64*)cur, grp_out + 20 * (size_t)g, gr.nw, c,
                                g > 0 ? (const u64*)(grp_out + 20 * (size_t)(g - 1)) : (const u64*)nullptr);
             if (st != D.s()) HIP_TRY(hipEventRecord(D.ev_grp_done[g], st));
@@ -1098,8 +1155,10 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
         if (e == hipSuccess) {
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-            e = hipStreamCreateWithPriority(&ds.grp, hipStreamNonBlocking, tune.msm_tail_prio == 0 ? 0 : hi_p);
+            e = hipStreamCreateWithPriority(&ds.grp, hipStreamNonBlocking, ZC_MSM_TAIL_PRIO ? hi_p : 0);
         }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_digits, hipEventDisableTiming);
+        for (int g = 0; g < 4 && e == hipSuccess; g++) e = hipEventCreateWithFlags(&ds.ev_sorted[g], hipEventDisableTiming);
         for (int g = 0; g < 3 && e == hipSuccess; g++) {
             e = hipEventCreateWithFlags(&ds.ev_grp_go[g], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_grp_done[g], hipEventDisableTiming);
@@ -1115,6 +1174,13 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
     return ZC_OK;
 }
 
+int zc_ctx_device(zc_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= (int)ctx->devs.size()) return fail(ZC_ERR_BAD_ARG, "zc_ctx_device: no such device slot");
+    return ctx->devs[(size_t)slot].device;
+}
+int zc_ctx_device_count(zc_ctx* ctx) { return ctx ? (int)ctx->devs.size() : fail(ZC_ERR_BAD_ARG, "null context"); }
+
 int zc_ctx_destroy(zc_ctx* ctx)
 {
     if (!ctx) return ZC_OK;
@@ -1128,6 +1194,9 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
         if (ds.aux) (void)hipStreamDestroy(ds.aux);
         if (ds.grp) (void)hipStreamSynchronize(ds.grp), (void)hipStreamDestroy(ds.grp);
+        if (ds.ev_digits) (void)hipEventDestroy(ds.ev_digits);
+        for (int g = 0; g < 4; g++)
+            if (ds.ev_sorted[g]) (void)hipEventDestroy(ds.ev_sorted[g]);
         for (int g = 0; g < 3; g++) {
             if (ds.ev_grp_go[g]) (void)hipEventDestroy(ds.ev_grp_go[g]);
             if (ds.ev_grp_done[g]) (void)hipEventDestroy(ds.ev_grp_done[g]);
@@ -1202,9 +1271,12 @@ int zc_ctx_synchronize(zc_ctx* ctx)
 // ---- FieldElement
 int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, zc::k_fe_add_stream, a, b, o, n, 40); }
 int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, zc::k_fe_sub_stream, a, b, o, n, 40); }
-int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, nullptr, a, b, o, n, 40); }
+#ifndef ZC_MULSQ_STAGED
+#define ZC_MULSQ_STAGED 0            // A/B: the LDS-staged variants of mul / square beyond the Infinity Cache
+#endif
+int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, ZC_MULSQ_STAGED ? zc::k_fe_mul_stream : nullptr, a, b, o, n, 40); }
 int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
-int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40); }
+int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40, ZC_MULSQ_STAGED ? zc::k_fe_square_stream : nullptr); }
 
 // Montgomery's trick shares one inversion among the c consecutive elements of a lane (3 multiplications per
 // element + one inversion per lane).  c = cnt / INV_LANES_TARGET keeps that many lanes busy, capped at 64;
@@ -1352,9 +1424,11 @@ int zc_sc_from_bytes(zc_ctx* ctx, const uint8_t* in32, uint64_t* out, uint8_t* o
 int zc_sc_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n) { return zc_fe_to_bytes(ctx, in, out32, n); }
 
 // ---- EdwardsPoint
-int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, nullptr, p, q, o, n, 160); }
-int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, nullptr, p, q, o, n, 160); }
-int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160); }
+// staged records from 2^12 points on (below, a launch is a handful of workgroups and the barriers only cost)
+constexpr size_t ED_STAGED_MIN_BYTES = (size_t)160 * 3 << 12;
+int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, zc::k_ed_add_staged, p, q, o, n, 160, ED_STAGED_MIN_BYTES); }
+int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, zc::k_ed_sub_staged, p, q, o, n, 160, ED_STAGED_MIN_BYTES); }
+int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160, zc::k_ed_double_staged, ED_STAGED_MIN_BYTES); }
 int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160); }
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
@@ -1460,8 +1534,7 @@ int zc_ris_roundtrip_mul(zc_ctx* ctx, const uint8_t* in32, const uint64_t* k, ui
     int inner = ZC_OK;
     int rc = run_batched(ctx, args, 4, n, [&](void** d, size_t cnt, DevState& D) {
         if (D.tune.ristretto_strict) {
-            const zc::u32* idx = balance_index(D, (const u64*)d[1], cnt);
-            hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], idx, cnt);
+            hipLaunchKernelGGL(zc::k_ris_roundtrip_mul, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const uint8_t*)d[0], (const u64*)d[1], (uint8_t*)d[2], (uint8_t*)d[3], cnt);
             return;
         }
         inner = fast_ring(D, cnt, [&](zc::u32* table, zc::u32* ring, zc::u32 slots, size_t off, size_t c) {
@@ -1740,10 +1813,19 @@ int zc_test_msm_sort(zc_ctx* ctx, const uint64_t* scalars, size_t n, int c, uint
             continue;
         }
         hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(n)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)scalars, digits, n, c, W);
-        const uint2* sorted = nullptr;
-        int rc = msm_sort(D, plan, digits, pairs_a, pairs_b, table, sums, &sorted);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out_pairs, sorted, m * sizeof(uint2), hipMemcpyDeviceToDevice, D.s()));
+        // ZC_MSM_GROUPS that adds up to the windows: every group sorted on its own, top group first (as msm_on_device does)
+        int gsum = 0;
+        for (int g = 0; g < D.tune.msm_ngroups; g++) gsum += D.tune.msm_groups[g];
+        if (D.tune.msm_ngroups >= 2 && gsum == W) {
+            int top = W;
+            for (int g = 0; g < D.tune.msm_ngroups; g++) {
+                top -= D.tune.msm_groups[g];
+                if (int rc = msm_sort(D, D.s(), plan, top, D.tune.msm_groups[g], digits, pairs_a, pairs_b, table, plan.table_words, sums)) return rc;
+            }
+        } else if (int rc = msm_sort(D, D.s(), plan, 0, W, digits, pairs_a, pairs_b, table, plan.table_words, sums)) {
+            return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(out_pairs, pairs_a, m * sizeof(uint2), hipMemcpyDeviceToDevice, D.s()));
         HIP_TRY(hipStreamSynchronize(D.s()));
         HIP_TRY(hipGetLastError());
     }
@@ -1771,16 +1853,22 @@ int zc_test_odd_table(zc_ctx* ctx, uint64_t* out_dev_points)
 
 // What the bucket method would do for a shard of n pairs on this context (its knobs included) -- a query, no device
 // work.  A measurement aid: a roofline record counts the useful multiplications from c, W and the addition formula.
-// out8: [0] window bits c (0: below the bucket threshold, n scalar multiplications + folds), [1] windows W,
-// [2] 1 = affine 96-byte records / 7-multiplication additions, 0 = projective 128-byte / 8, [3] bytes per gathered
-// record, [4] run length T of the bucket-sum kernel, [5] buckets per reduction segment, [6] sort passes, [7] window groups.
-int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out8)
+// Writes min(nout, 17) entries (nout >= 8): [0] window bits c (0: below the bucket threshold, n scalar multiplications + folds),
+// [1] windows W, [2] 1 = affine records / 7-multiplication additions, 0 = projective / 8, [3] PAYLOAD bytes of a gathered
+// record (96 / 128), [4] run length of the bucket-sum kernel (window groups: the top group's), [5] buckets per reduction
+// segment, [6] sort passes, [7] window groups G, [8] record STRIDE in bytes (what a gather touches: one 128-byte line),
+// [9..12] windows per group (top group first), [13..16] run length per group.
+int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out, int nout)
 {
     if (!ctx) return fail(ZC_ERR_BAD_ARG, "null context");
-    REQUIRE(out8);
+    REQUIRE(out);
+    if (nout < 8) return fail(ZC_ERR_BAD_ARG, "zc_msm_plan: nout < 8");
     const MsmPlan p = msm_plan(n, points_aligned16 != 0, ctx->devs[0].tune);
-    const int32_t v[8] = {p.c, p.W, p.affine ? 1 : 0, p.buckets ? p.rec_bytes : 0, p.T, p.seg, p.sort.passes, p.buckets ? p.G : 0};
-    memcpy(out8, v, sizeof v);
+    if (p.bad_groups) return fail(ZC_ERR_BAD_ARG, "zc_msm_plan: ZC_MSM_GROUPS does not add up to this shard's window count");
+    const bool b = p.buckets;
+    const int32_t v[17] = {p.c, p.W, p.affine ? 1 : 0, b ? (p.affine ? 96 : 128) : 0, b ? p.gT[0] : 0, p.seg, p.sort.passes, b ? p.G : 0, b ? p.rec_bytes : 0,
+                           p.gw[0], p.gw[1], p.gw[2], p.gw[3], p.gT[0], p.gT[1], p.gT[2], p.gT[3]};
+    memcpy(out, v, sizeof(int32_t) * (size_t)std::min(nout, 17));
     return ZC_OK;
 }
 

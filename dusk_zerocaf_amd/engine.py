@@ -26,9 +26,10 @@ def _is_torch(x) -> bool:
 
 
 class Engine:
-    """One zc_ctx.  `devices=None` = one slot on torch's current device when torch is loaded and sees a GPU,
-    otherwise on device 0.  The context reads the library's tuning knobs (ZC_* environment variables,
-    INTEGRATION.md section 6) once, here.  `lib`: another build of the same ABI (tests: the ZC_TEST_HOOKS build)."""
+    """One zc_ctx.  `devices=None` = one slot on torch's current device when torch is loaded and sees a GPU; otherwise
+    zc_ctx_create(NULL, 0): the calling thread's current HIP device (whatever hipSetDevice chose), read back from the
+    context.  The context reads the library's tuning knobs (ZC_* environment variables)
+    once, here.  `lib`: another build of the same ABI (tests: the ZC_TEST_HOOKS build)."""
 
     def __init__(self, devices=None, lib=None):
         self.lib = lib if lib is not None else _lib.load()
@@ -38,12 +39,14 @@ class Engine:
         if not devices:
             import sys
             torch = sys.modules.get("torch")
-            devices = [torch.cuda.current_device()] if torch is not None and torch.cuda.is_available() else [0]
-        self._devices = list(devices)    # slot i of the context = HIP device _devices[i]; always known, so the
-                                         # ownership check of _follow_torch_stream always runs
-        arr = (C.c_int * len(self._devices))(*self._devices)
-        rc = self.lib.zc_ctx_create(arr, len(self._devices), C.byref(self.ctx))
+            devices = [torch.cuda.current_device()] if torch is not None and torch.cuda.is_available() else []
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        rc = self.lib.zc_ctx_create(arr, len(devices), C.byref(self.ctx))
         _lib.check(rc, "zc_ctx_create", self.lib)
+        # slot i of the context = HIP device _devices[i], as the context itself reports it: always known, so the
+        # ownership check of _follow_torch_stream always runs
+        self._devices = [self.lib.zc_ctx_device(self.ctx, i) for i in range(self.lib.zc_ctx_device_count(self.ctx))]
+        assert not devices or self._devices == list(devices), (self._devices, devices)
 
     def close(self):
         if self.ctx:
@@ -425,10 +428,12 @@ class Engine:
 
     def msm_plan(self, n, points_aligned16=True):
         """What the bucket method would do for a shard of n pairs on this context (a query, no device work)."""
-        v = (C.c_int32 * 8)()
-        self._call("zc_msm_plan", int(n), 1 if points_aligned16 else 0, v)
-        return {"window_bits": v[0], "windows": v[1], "affine": bool(v[2]), "record_bytes": v[3], "run": v[4],
-                "segment_buckets": v[5], "sort_passes": v[6], "window_groups": v[7]}
+        v = (C.c_int32 * 17)()
+        self._call("zc_msm_plan", int(n), 1 if points_aligned16 else 0, v, 17)
+        g = v[7]
+        return {"window_bits": v[0], "windows": v[1], "affine": bool(v[2]), "record_bytes": v[3], "record_stride": v[8], "run": v[4],
+                "segment_buckets": v[5], "sort_passes": v[6], "window_groups": g,
+                "group_windows": [v[9 + i] for i in range(g)], "group_runs": [v[13 + i] for i in range(g)]}
 
     def ris_mul_base_compress(self, k):
         k, pk, n = self._prep(k, 5, np.uint64)

@@ -45,6 +45,14 @@ public:
     static void set_stream(void* hip_stream) { check(zc_ctx_set_stream(ctx(), hip_stream, 1), "zc_ctx_set_stream"); }
     static void use_own_stream() { check(zc_ctx_set_stream(ctx(), nullptr, 0), "zc_ctx_set_stream"); }
     static void synchronize() { check(zc_ctx_synchronize(ctx()), "zc_ctx_synchronize"); }
+    // the HIP device behind slot `slot` of the context (what zc_ctx_create(NULL, 0, ..) picked, or the list it was given)
+    static int device(int slot = 0)
+    {
+        const int d = zc_ctx_device(ctx(), slot);
+        if (d < 0) check(d, "zc_ctx_device");
+        return d;
+    }
+    static int slot_count() { return zc_ctx_device_count(ctx()); }
     static void set_stream_dev(int slot, void* hip_stream) { check(zc_ctx_set_stream_dev(ctx(), slot, hip_stream, 1), "zc_ctx_set_stream_dev"); }
     // pin a long-lived host buffer: host batches from it copy asynchronously
     static void host_register(void* p, size_t bytes) { check(zc_host_register(p, bytes), "zc_host_register"); }
@@ -623,11 +631,12 @@ inline std::vector<EdwardsPoint> window_naf_mul_batch(const std::vector<Scalar>&
     for (size_t i = 0; i < ks.size(); i++) out[i] = EdwardsPoint::unflat(&o[20 * i]);
     return out;
 }
-// the bucket method's plan for a shard of n pairs: {c, W, affine, record bytes, run, segment, sort passes, window groups}
-inline std::array<int32_t, 8> msm_plan(size_t n, bool points_aligned16 = true)
+// the bucket method's plan for a shard of n pairs: {c, W, affine, record payload bytes, run, segment, sort passes, window groups,
+// record stride, windows per group [4], run length per group [4]}
+inline std::array<int32_t, 17> msm_plan(size_t n, bool points_aligned16 = true)
 {
-    std::array<int32_t, 8> v{};
-    Backend::check(zc_msm_plan(Backend::ctx(), n, points_aligned16 ? 1 : 0, v.data()), "zc_msm_plan");
+    std::array<int32_t, 17> v{};
+    Backend::check(zc_msm_plan(Backend::ctx(), n, points_aligned16 ? 1 : 0, v.data(), 17), "zc_msm_plan");
     return v;
 }
 // key generation: (RISTRETTO_BASEPOINT * k).compress(), identical bytes

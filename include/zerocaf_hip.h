@@ -78,6 +78,10 @@ typedef enum zc_status {
  * of a running process changes nothing for a context that exists.               */
 int zc_ctx_create(const int *devices, int ndev, zc_ctx **out);
 int zc_ctx_destroy(zc_ctx *ctx);
+/* The HIP device behind device slot `slot` of the context (>= 0), or ZC_ERR_BAD_ARG; zc_ctx_device_count: its slots.
+ * (What zc_ctx_create(NULL, 0, ..) picked: the calling thread's current HIP device.)                                  */
+int zc_ctx_device(zc_ctx *ctx, int slot);
+int zc_ctx_device_count(zc_ctx *ctx);
 /* external != 0: launch on the caller's hipStream_t `hip_stream` (e.g.
  * torch.cuda.current_stream().cuda_stream; NULL there means the HIP null stream) for
  * device 0 of the context.  external == 0: go back to the context's own stream.   */
@@ -249,14 +253,18 @@ int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t 
  *                       A rank whose local part fails still joins the collective (with a poison
  *                       record) and EVERY rank returns an error: nobody is left waiting.
  *   zc_msm_plan         a query, no device work: what the bucket method would do for a shard of n pairs on this
- *                       context -- out8 = {window bits c (0: below the bucket threshold, n scalar multiplications +
- *                       folds), windows W, 1 = affine 96-byte records and 7-multiplication additions / 0 = projective
- *                       128-byte records and 8, bytes per gathered record, run length of the bucket-sum kernel,
- *                       buckets per reduction segment, sort passes, window groups}.  What a roofline record counts its useful
- *                       work from (bench.py); points_aligned16: whether the point array is 16-byte aligned.           */
+ *                       context.  Writes min(nout, 17) entries, nout >= 8: {window bits c (0: below the bucket
+ *                       threshold, n scalar multiplications + folds), windows W, 1 = affine records and
+ *                       7-multiplication additions / 0 = projective and 8, PAYLOAD bytes of a gathered record (96 /
+ *                       128), run length of the bucket-sum kernel (window groups: the top group's), buckets per
+ *                       reduction segment, sort passes, window groups G, record STRIDE in bytes, windows per group
+ *                       [4] (top group first), run length per group [4]}.  What a roofline record counts its useful
+ *                       work from (bench.py); points_aligned16: whether the point array is 16-byte aligned.
+ *                       A ZC_MSM_GROUPS split that does not add up to the shard's W windows makes zc_msm* and this
+ *                       query fail with ZC_ERR_BAD_ARG (never silently one group).                                     */
 int zc_msm_partial(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t n,
                    uint64_t *out_dev_point);
-int zc_msm_plan(zc_ctx *ctx, size_t n, int points_aligned16, int32_t *out8);
+int zc_msm_plan(zc_ctx *ctx, size_t n, int points_aligned16, int32_t *out, int nout);
 int zc_ed_fold_ordered(zc_ctx *ctx, const uint64_t *parts, size_t count, uint64_t *out);
 int zc_comm_unique_id(uint8_t *id_out128);
 int zc_comm_init(zc_ctx *ctx, const uint8_t *id128, int rank, int world);

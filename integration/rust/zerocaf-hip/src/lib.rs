@@ -247,6 +247,23 @@ impl HipBackend {
         check(unsafe { ffi::zc_ctx_synchronize(self.ctx) })
     }
 
+    /// The HIP devices behind the context's slots (what `zc_ctx_create(NULL, 0, ..)` picked, or the list it was given).
+    pub fn devices(&self) -> Result<Vec<i32>> {
+        let n = unsafe { ffi::zc_ctx_device_count(self.ctx) };
+        if n < 0 {
+            check(n)?;
+        }
+        (0..n)
+            .map(|slot| {
+                let d = unsafe { ffi::zc_ctx_device(self.ctx, slot) };
+                if d < 0 {
+                    check(d)?;
+                }
+                Ok(d)
+            })
+            .collect()
+    }
+
     // -------------------------------------------------------------- call shapes
     fn bin(&self, f: Bin, a: &[u64], b: &[u64], n: usize, wout: usize) -> Result<Vec<u64>> {
         let mut out = vec![0u64; n * wout];
@@ -572,10 +589,11 @@ impl HipBackend {
     }
 
     /// The bucket method's plan for a shard of `n` pairs on this context (a query, no device work):
-    /// `[c, W, affine, record bytes, run length, buckets per segment, sort passes, window groups]`.
-    pub fn msm_plan(&self, n: usize, points_aligned16: bool) -> Result<[i32; 8]> {
-        let mut v = [0i32; 8];
-        check(unsafe { ffi::zc_msm_plan(self.ctx, n, points_aligned16 as i32, v.as_mut_ptr()) })?;
+    /// `[c, W, affine, record payload bytes, run length, buckets per segment, sort passes, window groups, record stride,
+    /// windows per group x 4, run length per group x 4]`.
+    pub fn msm_plan(&self, n: usize, points_aligned16: bool) -> Result<[i32; 17]> {
+        let mut v = [0i32; 17];
+        check(unsafe { ffi::zc_msm_plan(self.ctx, n, points_aligned16 as i32, v.as_mut_ptr(), 17) })?;
         Ok(v)
     }
 

@@ -21,7 +21,7 @@ def lib():
     import dusk_zerocaf_amd as z
     if not os.path.exists(z.LIB_PATH):
         from dusk_zerocaf_amd import build
-        build.build()
+        build.build(test_hooks=True)
     return z.load()
 
 
@@ -78,6 +78,17 @@ def test_release_library_carries_no_test_hooks_and_reads_its_knobs_once(lib):
     body = body[:body.index("\n}\n")]
     outside = src.replace(body, "")
     assert re.findall(r"getenv\(\"(ZC_[A-Z_0-9]+)\"\)", outside) == ["ZC_RCCL_PATH"]     # where librccl lives: not a tuning knob
+    # the product's knob surface, from the shipped binary itself: nine tuning knobs.  The path
+    # forcers of the test tier exist in the -DZC_TEST_HOOKS build only; variants that were measured and lost are compile-time
+    # macros (build_variant), not switches
+    strings = lambda path: set(re.findall(rb"\x00(ZC_[A-Z][A-Z_0-9]+)(?=\x00)", open(path, "rb").read()))     # whole C strings
+    product = sorted(x.decode() for x in strings(z.LIB_PATH) if not x.startswith((b"ZC_ERR", b"ZC_OK")))
+    assert product == ["ZC_HOST_CHUNKS", "ZC_INV_CHUNK", "ZC_JACOBI_ROUNDS", "ZC_MSM_AFFINE", "ZC_MSM_GROUPS", "ZC_MSM_WINDOW", "ZC_RCCL_PATH",
+                       "ZC_RING_SLOTS", "ZC_RISTRETTO_STRICT", "ZC_SCHED"], product
+    hooks_only = sorted(x.decode() for x in strings(_lib.TEST_LIB_PATH) - strings(z.LIB_PATH))
+    assert hooks_only == ["ZC_MSM_AFFINE_CHUNK", "ZC_MSM_FORK", "ZC_MSM_RUN", "ZC_MSM_RUN_EDGES", "ZC_MSM_SEG", "ZC_MSM_SORT_BIG", "ZC_MSM_SORT_G",
+                          "ZC_MSM_SORT_PACKED", "ZC_TEST_RING_POISON", "ZC_TEST_RING_SPINS"], hooks_only
+    assert "PROBE" not in src                                # timing probes live in tools/debug/probes/*.patch
     assert "env_long(" in body and outside.count("env_long(") == 1                      # its definition only
 
 
@@ -169,20 +180,25 @@ def test_engine_binds_torch_streams_to_the_slot_that_owns_the_tensor():
 def test_default_engine_knows_its_device_so_the_ownership_check_always_runs():
     """`Engine()` (no device list) used to keep `_devices = None`, and a tensor on another GPU then got that
     GPU's torch stream bound to slot 0.  The constructor now always records the context's devices -- torch's current device
-    when torch sees a GPU, else device 0 -- so a foreign tensor is refused before anything is launched.  (No GPU needed: a
-    stand-in for the library records the zc_ctx_create call.)"""
+    when torch sees a GPU; otherwise zc_ctx_create(NULL, 0), i.e. whatever device the caller's hipSetDevice
+    chose, read back through zc_ctx_device -- so a foreign tensor is refused before anything is launched.  (No GPU needed:
+    a stand-in for the library records the zc_ctx_create call.)"""
     import types
     import dusk_zerocaf_amd as z
     from dusk_zerocaf_amd.engine import Engine
     seen = []
 
     def create(arr, n, out):
-        seen.append([arr[i] for i in range(n)])
+        seen.append(None if arr is None else [arr[i] for i in range(n)])
         return 0
     fake = types.SimpleNamespace(zc_ctx_create=create, zc_ctx_destroy=lambda ctx: 0, zc_last_error=lambda: b"",
-                                 zc_ctx_set_stream_dev=lambda ctx, slot, h, ext: 0)
+                                 zc_ctx_set_stream_dev=lambda ctx, slot, h, ext: 0,
+                                 zc_ctx_device=lambda ctx, slot: 3, zc_ctx_device_count=lambda ctx: 1)
     e = Engine(lib=fake)
-    assert seen == [[0]] and e._devices == [0]                  # no GPU visible here: device 0, explicitly
+    assert seen == [None] and e._devices == [3]                 # no torch GPU here: the library's own choice (the current HIP device), read back
+    e.ctx = None
+    fake.zc_ctx_device = lambda ctx, slot: 0
+    e = Engine(lib=fake)
     import torch
     orig = torch.cuda.current_stream
     torch.cuda.current_stream = lambda dev=None: types.SimpleNamespace(cuda_stream=0x1234)

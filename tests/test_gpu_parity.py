@@ -1021,9 +1021,11 @@ def test_msm_degenerate_scalars(eng, oracle):
     assert eq(oracle.ed_compress(eng.msm(P, K))[0], oracle.ed_compress(_gpu_naive_msm(eng, P, K))[0])
 
 
-def _msm_sort_model(K, c):
+def _msm_sort_model(K, c, groups=None):
     """numpy model of k_msm_digits + the bucket sort: pairs (window << (c-1) | |d| - 1, i | sign << 31) in
-    stable bucket order, the zero digits (key 0xFFFFFFFF) behind every bucket, window by window."""
+    stable bucket order, the zero digits (key 0xFFFFFFFF) behind every bucket, window by window.
+    `groups` (windows per group, top group first): every group of windows sorted on its own -- the same order inside
+    the group's own part of the list [w0 n, (w0 + nw) n), its zero digits at the end of that part."""
     n, W, half = len(K), -(-261 // c), 1 << (c - 1)
     key = np.zeros((W, n), dtype=np.int64)
     sign = np.zeros((W, n), dtype=np.uint32)
@@ -1045,16 +1047,27 @@ def _msm_sort_model(K, c):
         out_v.append((idx[nz] | (sign[w][nz] << np.uint32(31)))[order])
         tail_k.append(np.full(int((~nz).sum()), 0xFFFFFFFF, dtype=np.uint32))
         tail_v.append(idx[~nz] | (sign[w][~nz] << np.uint32(31)))       # raw = 2^c: a zero digit that still carries
-    return np.concatenate(out_k + tail_k), np.concatenate(out_v + tail_v)
+    if not groups:
+        return np.concatenate(out_k + tail_k), np.concatenate(out_v + tail_v)
+    assert sum(groups) == W
+    parts_k, parts_v, top = [], [], W
+    for nw in groups:                                             # top group first = the highest windows
+        top -= nw
+        parts_k.insert(0, np.concatenate(out_k[top:top + nw] + tail_k[top:top + nw]))
+        parts_v.insert(0, np.concatenate(out_v[top:top + nw] + tail_v[top:top + nw]))
+    return np.concatenate(parts_k), np.concatenate(parts_v)
 
 
-@pytest.mark.parametrize("n,c,g,packed", [(1000, 5, None, 1), (3 * 4096 + 17, 9, None, 1), (3 * 4096 + 17, 10, 2, 1), (3 * 4096 + 17, 10, 2, 0),
-                                          (70001, 13, None, 1), (70001, 17, 3, 1), (70001, 17, 3, 0), (40000, 19, None, 1),
-                                          (40000, 19, 2, 0), (40000, 19, 2, 2), (3 * 8192 + 5, 9, 2, 2), (20000, 20, None, 1), (9000, 22, 1, 1)])
-def test_msm_key_sort_is_the_stable_bucket_order(n, c, g, packed):
+@pytest.mark.parametrize("n,c,g,packed,groups", [
+    (1000, 5, None, 1, None), (3 * 4096 + 17, 9, None, 1, None), (3 * 4096 + 17, 10, 2, 1, None), (3 * 4096 + 17, 10, 2, 0, None),
+    (70001, 13, None, 1, None), (70001, 17, 3, 1, None), (70001, 17, 3, 0, None), (40000, 19, None, 1, None),
+    (40000, 19, 2, 0, None), (40000, 19, 2, 2, None), (3 * 8192 + 5, 9, 2, 2, None), (20000, 20, None, 1, None), (9000, 22, 1, 1, None),
+    (70001, 17, 3, 1, "9,4,3"), (70001, 17, 3, 0, "15,1"), (3 * 8192 + 5, 9, 2, 2, "10,10,8,1"), (1000, 5, None, 1, "1,52"), (20000, 20, None, 1, "7,7")])
+def test_msm_key_sort_is_the_stable_bucket_order(n, c, g, packed, groups):
     """The hand-written per-window LSD counting sort (zc_sort.hip.h) through its test hook: one, two and three
     passes, the one-word and the two-word intermediate of the two-pass sort, partial tiles, several tiles per
-    column, skewed digits -- pair for pair the stable sort's output."""
+    column, skewed digits -- pair for pair the stable sort's output.  With `groups`: every group of windows sorted
+    on its own, top group first (the pipeline's order), each in its own part of the list."""
     import torch
     K = V.rand_scalars_np(n, V.SEED + 300 + c, bits=252)
     K[0] = 0
@@ -1066,10 +1079,10 @@ def test_msm_key_sort_is_the_stable_bucket_order(n, c, g, packed):
     out = torch.empty((n * W, 2), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     # 0: two-word intermediate, 2: with tiles of 8192 keys; the hook lives in the -DZC_TEST_HOOKS build only
-    with V.tuned(hooks=True, ZC_MSM_SORT_G=g, ZC_MSM_SORT_PACKED="1" if packed == 1 else "0", ZC_MSM_SORT_BIG="1" if packed == 2 else "0") as te:
+    with V.tuned(hooks=True, ZC_MSM_SORT_G=g, ZC_MSM_SORT_PACKED="1" if packed == 1 else "0", ZC_MSM_SORT_BIG="1" if packed == 2 else "0", ZC_MSM_GROUPS=groups) as te:
         assert te.lib.zc_test_msm_sort(te.ctx, dK.data_ptr(), n, c, out.data_ptr()) == 0, te.lib.zc_last_error()
     got = out.cpu().numpy().view(np.uint32)
-    wk, wv = _msm_sort_model(K, c)
+    wk, wv = _msm_sort_model(K, c, [int(x) for x in groups.split(",")] if groups else None)
     assert eq(got[:, 0], wk)
     assert eq(got[:, 1], wv)
 
@@ -1142,24 +1155,24 @@ def test_msm_skewed_digit_distributions(eng, oracle):
         want = oracle.msm_naive_mt(P, K)
         wenc = oracle.ed_compress(want)[0]
         for run, c in ((None, None), (4, 8), (5, 11), (7, None), (64, 6), (4096, None)):
-            with V.tuned(ZC_MSM_RUN=run, ZC_MSM_WINDOW=c) as te:
+            with V.tuned(hooks=True, ZC_MSM_RUN=run, ZC_MSM_WINDOW=c) as te:
                 got = te.msm(P, K)
             assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), (name, run, c)
 
 
 @pytest.mark.parametrize("knobs", [
-    dict(ZC_MSM_AFFINE=0), dict(ZC_MSM_AFFINE=0, ZC_MSM_FORK=1), dict(ZC_MSM_FORK=0), dict(ZC_MSM_FORK=1),
-    dict(ZC_MSM_RUN_EDGES=4), dict(ZC_MSM_RUN_EDGES=32, ZC_MSM_RUN=16), dict(ZC_MSM_AFFINE_CHUNK=1), dict(ZC_MSM_AFFINE_CHUNK=5, ZC_MSM_SEG=4),
-    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12), dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=6, ZC_MSM_RUN=128), dict(ZC_MSM_GROUPS="17,4"), dict(ZC_MSM_GROUPS="12,5,4", ZC_MSM_SEG_QUAD=0),
-    dict(ZC_MSM_GROUPS="6,5,5,5", ZC_MSM_SEG_QUAD=1 << 20), dict(ZC_MSM_GROUPS="11,6,4", ZC_MSM_TAIL_SIDE=0, ZC_MSM_GROUP_WGS=0),
-    dict(ZC_MSM_GROUPS="9,8,4", ZC_MSM_GROUP_LANES=19, ZC_MSM_GROUP_WGS=2, ZC_MSM_TAIL_PRIO=0), dict(ZC_MSM_GROUPS="20,1", ZC_MSM_AFFINE=0), dict(ZC_MSM_REC_STRIDE=96), dict(ZC_MSM_FOLD_QUAD=0), dict(ZC_MSM_FOLD_QUAD=0, ZC_MSM_GROUPS="8,8,5", ZC_MSM_SEG=4),
-    dict(ZC_MSM_REC_STRIDE=96, ZC_MSM_GROUPS="10,11", ZC_MSM_AFFINE_CHUNK=3)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+    dict(ZC_MSM_AFFINE=0), dict(ZC_MSM_GROUPS="17,4"), dict(ZC_MSM_GROUPS="12,5,4"), dict(ZC_MSM_GROUPS="6,5,5,5"), dict(ZC_MSM_GROUPS="20,1", ZC_MSM_AFFINE=0),
+    # path forcers (the -DZC_TEST_HOOKS build reads them; the product takes these paths at other shard sizes)
+    dict(ZC_MSM_AFFINE=0, ZC_MSM_FORK=1), dict(ZC_MSM_FORK=0), dict(ZC_MSM_RUN_EDGES=4), dict(ZC_MSM_RUN_EDGES=32, ZC_MSM_RUN=16),
+    dict(ZC_MSM_AFFINE_CHUNK=1), dict(ZC_MSM_AFFINE_CHUNK=5, ZC_MSM_SEG=4), dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=12),
+    dict(ZC_MSM_SEG=64, ZC_MSM_WINDOW=6, ZC_MSM_RUN=128), dict(ZC_MSM_GROUPS="8,8,5", ZC_MSM_SEG=4), dict(ZC_MSM_GROUPS="10,11", ZC_MSM_AFFINE_CHUNK=3)],
+    ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
-    """Every MSM path a ZC_* knob can select in the shipped library (projective 128-byte records at a size where the
-    default is affine, the normalisation forked onto the second stream or kept in line, other edge-run lengths, other
-    normalisation chunkings and segment lengths, the windows in two / three / four groups with their chains on the side
-    stream or in line, four lanes per segment or one), at 2^17 + 333 pairs (where the affine path and the persistent
-    structures are live), against the ORACLE's sum of the reference's Mul<Scalar> + Add."""
+    """Every MSM path a knob can select -- the product's own (projective 128-byte records at a size where the default is affine,
+    the windows in two / three / four groups) and, through the test-hooks build of the same sources, the paths the product takes
+    at other shard sizes (normalisation forked or in line, other edge-run lengths, normalisation chunkings and segment lengths) --
+    at 2^17 + 333 pairs (where the affine path and the persistent structures are live), against the ORACLE's sum of the
+    reference's Mul<Scalar> + Add."""
     n = (1 << 17) + 333
     P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 410, bits=249))
     K = V.rand_scalars_np(n, V.SEED + 411, bits=252)
@@ -1167,29 +1180,59 @@ def test_msm_every_selectable_path_vs_oracle(eng, oracle, knobs):
     P[30] = V.IDENT_ROW
     want = oracle.msm_naive_mt(P, K)
     wenc = oracle.ed_compress(want)[0]
-    with V.tuned(**knobs) as te:
+    import dusk_zerocaf_amd as z
+    hooks = any(k not in ("ZC_MSM_AFFINE", "ZC_MSM_GROUPS", "ZC_MSM_WINDOW") for k in knobs)
+    with V.tuned(hooks=hooks, **knobs) as te:
         if "ZC_MSM_GROUPS" in knobs:                              # the split is really in force (it must add up to the windows)
-            assert te.msm_plan(n)["window_groups"] == len(knobs["ZC_MSM_GROUPS"].split(",")) and te.msm_plan(n)["windows"] == 21
+            gw = [int(x) for x in knobs["ZC_MSM_GROUPS"].split(",")]
+            plan = te.msm_plan(n)
+            assert plan["window_groups"] == len(gw) and plan["windows"] == 21 and plan["group_windows"] == gw and len(plan["group_runs"]) == len(gw)
         if knobs.get("ZC_MSM_WINDOW") == 6:                       # 32 buckets per window: a 64-bucket segment is cut down to the window
             assert te.msm_plan(n)["segment_buckets"] == 32 and te.msm_plan(n)["windows"] == 44
         got = te.msm(P, K)
         assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], wenc), knobs
         for _ in range(2):                                        # and again: the side stream's events and the workspace are reused
             assert eq(te.msm(P, K), got), knobs
-        small = te.msm(P[:5000], K[:5000])                         # and a shard below the affine threshold under the same knobs
-    wsmall = oracle.msm_naive_mt(P[:5000], K[:5000])
-    assert oracle.ed_eq(small, wsmall)[0] == 1, knobs
-    with V.tuned(ZC_MSM_AFFINE=1, **{k: v for k, v in knobs.items() if k != "ZC_MSM_AFFINE"}) as te:
-        assert oracle.ed_eq(te.msm(P[:5000], K[:5000]), wsmall)[0] == 1, knobs      # affine records forced on a small shard
+        wsmall = oracle.msm_naive_mt(P[:5000], K[:5000])
+        if "ZC_MSM_GROUPS" in knobs:
+            # a split that does not add up to the windows of THIS shard fails the call -- it is not silently replaced by one group
+            with pytest.raises(z.ZerocafHipError, match="ZC_MSM_GROUPS adds up to 21 windows"):
+                te.msm(P[:5000], K[:5000])
+            with pytest.raises(z.ZerocafHipError):
+                te.msm_plan(5000)
+            assert eq(te.msm(P, K), got), knobs                   # and the context is still good
+        else:
+            small = te.msm(P[:5000], K[:5000])                     # and a shard below the affine threshold under the same knobs
+            assert oracle.ed_eq(small, wsmall)[0] == 1, knobs
+    if "ZC_MSM_GROUPS" not in knobs:
+        with V.tuned(hooks=hooks, ZC_MSM_AFFINE=1, **{k: v for k, v in knobs.items() if k != "ZC_MSM_AFFINE"}) as te:
+            assert oracle.ed_eq(te.msm(P[:5000], K[:5000]), wsmall)[0] == 1, knobs      # affine records forced on a small shard
 
 
-@pytest.mark.parametrize("knobs", [dict(ZC_SCHED="block"), dict(ZC_SCHED="block", ZC_BALANCE="global"), dict(ZC_BALANCE="global")],
-                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_product_library_ignores_the_test_only_knobs(eng):
+    """libzerocaf_hip.so reads ten knobs; the path forcers exist in the -DZC_TEST_HOOKS build only,
+    and the variants that were measured and lost are compile-time macros (no runtime switch in either build)."""
+    n = (1 << 17) + 333
+    base = eng.msm_plan(n)
+    with V.tuned(ZC_MSM_RUN=16, ZC_MSM_SEG=4, ZC_MSM_SORT_PACKED=0, ZC_MSM_REC_STRIDE=96, ZC_MSM_FOLD_QUAD=0, ZC_BALANCE="global") as te:
+        assert te.msm_plan(n) == base
+    with V.tuned(hooks=True, ZC_MSM_RUN=16, ZC_MSM_SEG=4, ZC_MSM_REC_STRIDE=96) as te:
+        p = te.msm_plan(n)
+        assert p["run"] == 16 and p["segment_buckets"] == 4 and p["record_stride"] == 128 and p["record_bytes"] == 96
+    import subprocess
+    import dusk_zerocaf_amd as z
+    import re
+    txt = subprocess.run(["strings", z.LIB_PATH], capture_output=True, text=True).stdout
+    knobs = sorted(set(re.findall(r"^ZC_[A-Z_0-9]+$", txt, flags=re.M)))
+    assert knobs == ["ZC_HOST_CHUNKS", "ZC_INV_CHUNK", "ZC_JACOBI_ROUNDS", "ZC_MSM_AFFINE", "ZC_MSM_GROUPS", "ZC_MSM_WINDOW", "ZC_RCCL_PATH", "ZC_RING_SLOTS",
+                     "ZC_RISTRETTO_STRICT", "ZC_SCHED"], knobs
+
+
+@pytest.mark.parametrize("knobs", [dict(ZC_SCHED="block")], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_strict_scalar_mul_every_selectable_schedule_vs_oracle(eng, oracle, knobs):
-    """The strict kernels behind ZC_SCHED / ZC_BALANCE -- one workgroup per 256 elements with the block-local ranking
-    (`k_ed_scalar_mul` at >= 2^17 elements), the same kernels on the batch-wide cost-sorted permutation (the `idx`
-    branch of ed_scalar_mul_body) -- every (X:Y:Z:T) limb against the oracle's double_and_add (edwards.rs:102-120),
-    raw scalars >= 2^256 included, at 2^17 + 333 and at a size below the persistent-wave threshold."""
+    """The strict kernel behind ZC_SCHED=block -- one workgroup per 256 elements with the block-local ranking
+    (`k_ed_scalar_mul` at >= 2^17 elements) -- every (X:Y:Z:T) limb against the oracle's double_and_add
+    (edwards.rs:102-120), raw scalars >= 2^256 included, at 2^17 + 333 and at a size below the persistent-wave threshold."""
     n = (1 << 17) + 333
     P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 420, bits=249))
     K = V.rand_scalars_np(n, V.SEED + 421, bits=252)
@@ -1201,15 +1244,14 @@ def test_strict_scalar_mul_every_selectable_schedule_vs_oracle(eng, oracle, knob
     assert eq(eng.ed_scalar_mul(P, K), want)
     with V.tuned(**knobs) as te:
         assert eq(te.ed_scalar_mul(P, K), want), knobs
-        m = (1 << 14) + 77                                         # block-shaped launch (and the permutation from 2^14 elements on)
+        m = (1 << 14) + 77                                         # block-shaped launch
         assert eq(te.ed_scalar_mul(P[n - m:], K[n - m:]), want[n - m:]), knobs
         import torch
         dP, dK = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, K))
         assert eq(te.ed_scalar_mul(dP, dK).cpu().numpy().view(np.uint64), want), knobs
 
 
-@pytest.mark.parametrize("knobs", [dict(ZC_RISTRETTO_STRICT=1), dict(ZC_RISTRETTO_STRICT=1, ZC_BALANCE="global")],
-                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+@pytest.mark.parametrize("knobs", [dict(ZC_RISTRETTO_STRICT=1)], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_ristretto_roundtrip_strict_sequence_kernel_vs_oracle(eng, oracle, knobs):
     """ZC_RISTRETTO_STRICT=1 runs the fused config-4 kernel on the reference's formula sequence (`k_ris_roundtrip_mul`,
     ristretto.rs:96-154 -> edwards.rs:102-120 -> ristretto.rs:398-425) instead of the windowed core: every output byte

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Times zc_msm (device-resident inputs, result to the host: the synchronising call the sharded MSM makes) for window-group
 splits of the bucket pipeline.  Usage: python tools/msm_groups_sweep.py LOG2N [groups ...] with groups like 16 | 13,3 | 7,6,3
-(windows per group, top group first; must add up to the shard's window count) or "default"; extra knobs as K=V words."""
+(windows per group, top group first; must add up to the shard's window count) or "default"; extra knobs as K=V words
+(the path forcers are read by the -DZC_TEST_HOOKS build only: `HOOKS=1` as a word selects it; compile-time variants are
+libraries of their own: `python -m dusk_zerocaf_amd.build --variant NAME ZC_MSM_...=V`, then ZC_LIB_PATH=build/variants/NAME.so)."""
 import json
 import os
 import sys
@@ -19,6 +21,9 @@ def main():
     lg = int(sys.argv[1])
     specs = [a for a in sys.argv[2:] if "=" not in a] or ["1", "default"]
     extra = dict(a.split("=", 1) for a in sys.argv[2:] if "=" in a)
+    hooks = extra.pop("HOOKS", None)
+    from dusk_zerocaf_amd import _lib
+    lib = _lib.load_test_hooks() if hooks else None
     n = 1 << lg
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
     e0 = z.Engine()
@@ -31,7 +36,7 @@ def main():
         if spec != "default":
             os.environ["ZC_MSM_GROUPS"] = spec
         os.environ.update(extra)
-        eng = z.Engine()
+        eng = z.Engine(lib=lib)
         for k in list(extra) + ["ZC_MSM_GROUPS"]:
             os.environ.pop(k, None)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -13,14 +13,17 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dusk_zerocaf_amd as z  # noqa: E402
+from dusk_zerocaf_amd import _lib  # noqa: E402
 from oracle import zc_ref  # noqa: E402
 from tests import vectors as V  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 eng = z.Engine()
 zc_ref.build()
+# the product's own knobs + the path forcers of the -DZC_TEST_HOOKS build (the soak runs on that build: same sources)
 KNOBS = ("ZC_MSM_WINDOW", "ZC_MSM_AFFINE", "ZC_MSM_SORT_PACKED", "ZC_MSM_SORT_BIG", "ZC_MSM_RUN", "ZC_MSM_SORT_G", "ZC_MSM_AFFINE_CHUNK",
-         "ZC_MSM_GROUPS", "ZC_MSM_REC_STRIDE", "ZC_MSM_SEG", "ZC_MSM_SEG_QUAD", "ZC_MSM_GROUP_LANES", "ZC_MSM_TAIL_SIDE", "ZC_MSM_RUN_EDGES", "ZC_MSM_FORK", "ZC_MSM_FOLD_QUAD")
+         "ZC_MSM_GROUPS", "ZC_MSM_SEG", "ZC_MSM_RUN_EDGES", "ZC_MSM_FORK")
+HOOKS = _lib.load_test_hooks()
 for seed in range(first, first + count):
     t0 = time.time()
     rng = np.random.default_rng(0xB0C4E7 + seed)
@@ -42,22 +45,16 @@ for seed in range(first, first + count):
     if rng.random() < 0.3:
         knobs["ZC_MSM_AFFINE_CHUNK"] = int(rng.choice([1, 2, 5, 8, 16, 33]))
     if rng.random() < 0.3:
-        knobs["ZC_MSM_REC_STRIDE"] = int(rng.choice([96, 128]))
-    if rng.random() < 0.3:
         knobs["ZC_MSM_SEG"] = int(rng.choice([2, 4, 8, 16, 32, 64]))
-    if rng.random() < 0.3:
-        knobs["ZC_MSM_SEG_QUAD"] = int(rng.choice([0, 1 << 20]))
     if rng.random() < 0.2:
         knobs["ZC_MSM_RUN_EDGES"] = int(rng.choice([4, 6, 8, 16, 32]))
     if rng.random() < 0.2:
         knobs["ZC_MSM_FORK"] = int(rng.integers(0, 2))
-    if rng.random() < 0.3:
-        knobs["ZC_MSM_FOLD_QUAD"] = 0
     for k, v in knobs.items():
         os.environ[k] = str(v)
     if rng.random() < 0.6:
         # window groups: a random split of the windows this shard will have under the knobs above (the plan says how many)
-        probe = z.Engine()
+        probe = z.Engine(lib=HOOKS)
         W = probe.msm_plan(n)["windows"]
         probe.close()
         G = int(rng.integers(2, 5))
@@ -66,13 +63,7 @@ for seed in range(first, first + count):
             parts = [b - a for a, b in zip([0] + cuts, cuts + [W])]
             knobs["ZC_MSM_GROUPS"] = ",".join(str(x) for x in parts)
             os.environ["ZC_MSM_GROUPS"] = knobs["ZC_MSM_GROUPS"]
-            if rng.random() < 0.3:
-                knobs["ZC_MSM_GROUP_LANES"] = int(rng.integers(15, 20))
-                os.environ["ZC_MSM_GROUP_LANES"] = str(knobs["ZC_MSM_GROUP_LANES"])
-            if rng.random() < 0.2:
-                knobs["ZC_MSM_TAIL_SIDE"] = 0
-                os.environ["ZC_MSM_TAIL_SIDE"] = "0"
-    meng = z.Engine()                                              # the library reads its knobs when a context is created
+    meng = z.Engine(lib=HOOKS)                                     # the library reads its knobs when a context is created
     bits = int(rng.choice([16, 64, 128, 249, 252]))
     K = V.rand_scalars_np(n, seed * 7 + 1, bits=252)
     if bits < 249:
