@@ -476,6 +476,189 @@ ZC_DI void fe_to_limbs52(u64 (&l)[5], const fe& c)
     }
 }
 
+// ---------------------------------------------------------------- one-pass product (stand-alone mul / square kernels)
+// The stand-alone Mul / Square kernels take plain operands and return the plain canonical product (field.rs:250-262,
+// :302-315: the reference pays two Montgomery passes for that, mul_internal + montgomery_reduce twice).  Round 1-4 did the
+// same on the GPU (270 / 234 v_mad_u64_u32 per product).  For a canonical operand pair the special form of the moduli
+// gives the product in ONE pass: N = 2^T + c with c < 2^125, so 2^T = -c (mod N).  With one operand scaled by 2^PSHIFT
+// (PSHIFT = 261 - T: free, it happens in the radix conversion) the split point sits on the limb boundary 9 x 29 = 261:
+//     X' = a (b 2^S) = LO' + HI 2^261                      81 products (45 for a square), HI = limbs 9..17 as they are
+//     W  = LO' - HI (c 2^S)                                 45 products, signed columns; W = WLO + WH 2^261, -2^126 < WH <= 0
+//     R' = WLO - WH (c 2^S)     in [0, 1.5 2^261)           25 products; one conditional subtraction of N 2^S
+// and R' / 2^S is the canonical a b mod N (every term is a multiple of 2^S): 151 / 115 multiply-adds, no domain change.
+// Canonical outputs are the reference's limbs whatever algorithm produced them (SURVEY 8a note P).  Operands at or
+// above 2^T (non-canonical patterns, and the 2^-127 sliver [2^T, N)) take the two-pass form (per lane: fe_mulmod_limbs52).
+#ifndef ZC_MULSQ_ONEPASS
+#define ZC_MULSQ_ONEPASS 1      // 0: A/B build on the two Montgomery passes of rounds 1-4
+#endif
+// value * 2^sh of five 52-bit limbs -> nine normalized 29-bit limbs (value < 2^(261 - sh))
+ZC_DI fe fe_from_limbs52_shl(const u64 (&l)[5], const int sh)
+{
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k - sh;                          // bit of the unscaled value that lands on bit 0 of limb k
+        u64 x = 0;
+        if (bit < 0) {
+            x = (l[0] & M52) << (-bit);
+        } else {
+            const int idx = bit / 52, off = bit % 52;
+            if (idx < 5) {
+                x = (l[idx] & M52) >> off;
+                if (off + 29 > 52 && idx + 1 < 5) x |= (l[idx + 1] & M52) << (52 - off);
+            }
+        }
+        r.v[k] = (u32)x & M29;
+    }
+    return r;
+}
+// nine limbs (limbs 0..7 normalized, limb 8 may carry bit 29) holding value * 2^sh -> five 52-bit limbs of value
+ZC_DI void fe_to_limbs52_shr(u64 (&l)[5], const fe& c, const int sh)
+{
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int lo = 29 * k - sh - 52 * j;
+            if (lo > -32 && lo < 52) {
+                if (lo >= 0) acc |= (u64)c.v[k] << lo;
+                else acc |= (u64)c.v[k] >> (-lo);
+            }
+        }
+        l[j] = (j < 4) ? (acc & M52) : acc;
+    }
+}
+// x - n when that is not negative (limbs 0..7 normalized, limb 8 compared as it is)
+ZC_DI fe fe_cond_sub_limbs(const fe& x, const u32 (&n)[9])
+{
+    fe d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 s = x.v[k] - n[k] - borrow;
+        borrow = s >> 31;
+        d.v[k] = s & M29;
+    }
+    const u32 s8 = x.v[8] - n[8] - borrow;
+    d.v[8] = s8;
+    return fe_select((s8 >> 31) != 0, x, d);
+}
+// x[0..17]: the normalized limbs of X' = a b 2^PSHIFT (a, b < 2^TOPBIT).  Returns (a b mod N) 2^PSHIFT, canonical.
+template <class F>
+ZC_DI fe plain_fold_canon(const u32 (&x)[18])
+{
+    typedef long long i64;
+    ZC_ASSERT(x[17] < (1u << (F::TOPBIT - 232)));                          // HI < 2^TOPBIT
+    int32_t ndp[5];                                                        // -(c << PSHIFT), limb by limb: signed multiply-adds subtract
+#pragma unroll
+    for (int j = 0; j < 5; j++) ndp[j] = -(int32_t)F::DP[j];
+    // W = LO' - HI (c 2^S): columns 0..12 and the signed carry out of them
+    int32_t wh[5];
+    u32 w[9];
+    i64 col = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        if (k < 9) col += (i64)x[k];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 5) {
+                col += (i64)(int32_t)x[9 + i] * (i64)ndp[k - i];
+                ZC_PIN(col);
+            }
+        if (k < 9) w[k] = (u32)col & M29;
+        else wh[k - 9] = (int32_t)((u32)col & M29);
+        col >>= 29;                                                        // arithmetic: the columns are signed
+    }
+    ZC_ASSERT(col <= 0 && col > -(1 << 12));
+    wh[4] = (int32_t)col;                                                  // WH = wh[0..3] + wh[4] 2^116 <= 0
+    // R' = WLO - WH (c 2^S) >= 0: columns 0..8, limb 8 keeps what is left
+    fe r;
+    i64 c2 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        c2 += (i64)w[k];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+            if (k - i >= 0 && k - i < 5) {
+                c2 += (i64)wh[i] * (i64)ndp[k - i];
+                ZC_PIN(c2);
+            }
+        if (k < 8) {
+            r.v[k] = (u32)c2 & M29;
+            c2 >>= 29;
+        }
+    }
+    ZC_ASSERT(c2 >= 0 && c2 < (3ll << 28));                                // R' < 1.5 2^261
+    r.v[8] = (u32)c2;
+    return fe_cond_sub_limbs(r, F::NS);                                    // R' < 2 (N 2^S): one subtraction
+}
+// a b mod N for plain five-limb operands, canonical five-limb result
+template <class F>
+ZC_DI void fe_mulmod_limbs52(u64 (&r)[5], const u64 (&xa)[5], const u64 (&xb)[5])
+{
+    constexpr int TOP = F::TOPBIT - 208;                                   // bits of limb 4 below 2^TOPBIT
+    if (!ZC_MULSQ_ONEPASS || (((xa[4] | xb[4]) & M52) >> TOP) != 0) {     // an operand at or above 2^TOPBIT: (a R) b / R as before
+        const fe am = mont_to<F>(fe_from_limbs52(xa));
+        fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(mont_mul<F>(am, fe_from_limbs52(xb)))));
+        return;
+    }
+    const fe a = fe_from_limbs52(xa), b = fe_from_limbs52_shl(xb, F::PSHIFT);
+    u32 x[18];
+    u64 col = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) {
+                col += (u64)a.v[i] * b.v[k - i];
+                ZC_PIN(col);
+            }
+        x[k] = (u32)col & M29;
+        col >>= 29;
+    }
+    x[17] = (u32)col;
+    fe_to_limbs52_shr(r, plain_fold_canon<F>(x), F::PSHIFT);
+}
+// a^2 mod N likewise: a^2 2^S = (1 + (S & 1)) (a 2^(S / 2))^2, so the square keeps its 45 products
+template <class F>
+ZC_DI void fe_sqrmod_limbs52(u64 (&r)[5], const u64 (&xa)[5])
+{
+    constexpr int TOP = F::TOPBIT - 208, ODD = F::PSHIFT & 1;
+    if (!ZC_MULSQ_ONEPASS || ((xa[4] & M52) >> TOP) != 0) {
+        const fe a = fe_from_limbs52(xa);                     // any 260-bit pattern: (a R) a / R, within mont_mul's bounds
+        fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(mont_mul<F>(mont_to<F>(a), a))));
+        return;
+    }
+    const fe a = fe_from_limbs52_shl(xa, F::PSHIFT / 2);     // < 2^(TOPBIT + S / 2) < 2^261: normalized limbs
+    u32 d[9], e[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        d[i] = a.v[i] << (1 + ODD);                           // cross terms: 2 a_i a_j (times 2 when S is odd), < 2^31
+        e[i] = a.v[i] << ODD;
+    }
+    u32 x[18];
+    u64 col = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            if (k - i > i && k - i < 9) {
+                col += (u64)d[i] * a.v[k - i];
+                ZC_PIN(col);
+            }
+            if (k - i == i) {
+                col += (u64)e[i] * a.v[i];
+                ZC_PIN(col);
+            }
+        }
+        x[k] = (u32)col & M29;
+        col >>= 29;
+    }
+    x[17] = (u32)col;
+    fe_to_limbs52_shr(r, plain_fold_canon<F>(x), F::PSHIFT);
+}
+
 // load a reference-layout element and enter Montgomery form
 template <class F>
 ZC_DI fe fe_load_mont(const u64* __restrict__ p)

@@ -175,22 +175,13 @@ template <class F> struct OpNeg {
         sub52(r, z, x, m);
     }
 };
-// plain operands -> a*b mod N canonical: (a*R) * b / R, then canonicalise (value < 3N)
+// plain operands -> a*b mod N canonical, in one pass (zc_arith.hip.h: fe_mulmod_limbs52; operands at or above 2^TOPBIT
+// take the two Montgomery passes of rounds 1-4)
 template <class F> struct OpMul {
-    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&y)[5])
-    {
-        const fe am = mont_to<F>(fe_from_limbs52(x));
-        const fe p = mont_mul<F>(am, fe_from_limbs52(y));
-        fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(p)));
-    }
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&y)[5]) { fe_mulmod_limbs52<F>(r, x, y); }
 };
 template <class F> struct OpSqr {
-    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&)[5])
-    {
-        const fe s = mont_sqr<F>(fe_from_limbs52(x));       // a^2 / R
-        const fe p = mont_mul<F>(s, fe_const<F>(F::RR));
-        fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(p)));
-    }
+    static ZC_DI void apply(u64 (&r)[5], const u64 (&x)[5], const u64 (&)[5]) { fe_sqrmod_limbs52<F>(r, x); }
 };
 
 #define ZC_ELEMENTWISE2(name, OP)                                                                       \
@@ -514,20 +505,28 @@ ZC_KERNEL void k_ed_double(const u64* p, u64* out, size_t n)
 // piece.  Staged, the block's 256 records (40 KB, contiguous) move with coalesced 16-byte loads and stores, one operand
 // after the other through ONE 40 KB buffer (four workgroups per CU; the kernels hold three waves per SIMD anyway), and
 // the results leave the same way.  Same formulas, same limbs.
+#ifndef ZC_ED_STAGED_BLOCK
+#define ZC_ED_STAGED_BLOCK 256          // threads per workgroup of the staged point kernels (A/B: 64 / 128 / 256)
+#endif
+constexpr int ED_STAGED_BLOCK = ZC_ED_STAGED_BLOCK;
 template <int OP>                       // 0: add, 1: sub, 2: double
 ZC_DI void ed_binop_staged(const u64* p, const u64* q, u64* out, size_t n)
 {
-    __shared__ __attribute__((aligned(16))) u64 sp[ZC_BLOCK * 20];
-    const size_t base = (size_t)blockIdx.x * ZC_BLOCK;
-    const int cnt = (int)((n - base < (size_t)ZC_BLOCK) ? (n - base) : (size_t)ZC_BLOCK);
+    constexpr int B = ED_STAGED_BLOCK;
+    __shared__ __attribute__((aligned(16))) u64 sp[B * 20];
+    const size_t base = (size_t)blockIdx.x * B;
+    const int cnt = (int)((n - base < (size_t)B) ? (n - base) : (size_t)B);
     const int t = threadIdx.x;
-    coop_load40<false>(sp, p + 20 * base, cnt * 4);         // a point = four 40-byte records
+    const u64x2* gp = reinterpret_cast<const u64x2*>(p + 20 * base);
+    u64x2* lv = reinterpret_cast<u64x2*>(sp);
+    for (int v = t; v < cnt * 10; v += B) lv[v] = gp[v];       // a point = ten 16-byte pieces
     __syncthreads();
     pt a = pt_identity(), b;
     if (t < cnt) a = pt_load_plain(sp + 20 * t);
     if (OP != 2) {
         __syncthreads();                                     // every lane has its first operand: the buffer takes the second
-        coop_load40<false>(sp, q + 20 * base, cnt * 4);
+        const u64x2* gq = reinterpret_cast<const u64x2*>(q + 20 * base);
+        for (int v = t; v < cnt * 10; v += B) lv[v] = gq[v];
         __syncthreads();
         b = pt_identity();
         if (t < cnt) b = pt_load_plain(sp + 20 * t);
@@ -539,11 +538,13 @@ ZC_DI void ed_binop_staged(const u64* p, const u64* q, u64* out, size_t n)
     __syncthreads();                                         // ... and then the results
     if (t < cnt) pt_store_plain_r3(sp + 20 * t, r);
     __syncthreads();
-    coop_store40<false>(out + 20 * base, sp, cnt * 4);
+    u64x2* go = reinterpret_cast<u64x2*>(out + 20 * base);
+    for (int v = t; v < cnt * 10; v += B) go[v] = lv[v];
 }
-ZC_KERNEL void k_ed_add_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<0>(p, q, out, n); }
-ZC_KERNEL void k_ed_sub_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<1>(p, q, out, n); }
-ZC_KERNEL void k_ed_double_staged(const u64* p, u64* out, size_t n) { ed_binop_staged<2>(p, nullptr, out, n); }
+#define ZC_KERNEL_EDS extern "C" __global__ __launch_bounds__(ZC_ED_STAGED_BLOCK)
+ZC_KERNEL_EDS void k_ed_add_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<0>(p, q, out, n); }
+ZC_KERNEL_EDS void k_ed_sub_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<1>(p, q, out, n); }
+ZC_KERNEL_EDS void k_ed_double_staged(const u64* p, u64* out, size_t n) { ed_binop_staged<2>(p, nullptr, out, n); }
 ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();

@@ -414,7 +414,8 @@ int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint6
     Arg args[3] = {in_arg(a, elt ? elt : 160), in_arg(b, elt ? elt : 40), out_arg(out, elt ? elt : 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
         const bool stream = k_stream && cnt * elt * 3 > stream_min && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
-        hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
+        const unsigned blk = stream && elt == 160 ? (unsigned)zc::ED_STAGED_BLOCK : (unsigned)zc::ZC_BLOCK;     // the staged point kernels have their own workgroup size
+        hipLaunchKernelGGL(stream ? k_stream : k, dim3((unsigned)((cnt + blk - 1) / blk)), dim3(blk), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
     }, elt == 0);
 }
 int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_t elt, kun_t k_stream = nullptr, size_t stream_min = STREAM_BYTES)
@@ -423,7 +424,8 @@ int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_
     Arg args[2] = {in_arg(a, elt), out_arg(out, elt)};
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
         const bool stream = k_stream && cnt * elt * 2 > stream_min && aligned16(d[0]) && aligned16(d[1]);
-        hipLaunchKernelGGL(stream ? k_stream : k, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
+        const unsigned blk = stream && elt == 160 ? (unsigned)zc::ED_STAGED_BLOCK : (unsigned)zc::ZC_BLOCK;
+        hipLaunchKernelGGL(stream ? k_stream : k, dim3((unsigned)((cnt + blk - 1) / blk)), dim3(blk), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
 }
 
@@ -1271,12 +1273,18 @@ int zc_ctx_synchronize(zc_ctx* ctx)
 // ---- FieldElement
 int zc_fe_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_add, zc::k_fe_add_stream, a, b, o, n, 40); }
 int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_sub, zc::k_fe_sub_stream, a, b, o, n, 40); }
+// Mul / Square: LDS-staged beyond the Infinity Cache since round 5 -- with the one-pass product (151 / 115 multiply-adds instead of
+// 270 / 234) the staged kernels' coalesced traffic pays: 2^24 elements, same box, mul 0.411 -> 0.376 ms, square 0.273 -> 0.248
+// (with the two Montgomery passes of rounds 1-4 the staged kernels were the slower ones: 0.435 against 0.360 ms).
 #ifndef ZC_MULSQ_STAGED
-#define ZC_MULSQ_STAGED 0            // A/B: the LDS-staged variants of mul / square beyond the Infinity Cache
+#define ZC_MULSQ_STAGED 1            // 0: A/B build with per-lane accesses at every size
 #endif
-int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, ZC_MULSQ_STAGED ? zc::k_fe_mul_stream : nullptr, a, b, o, n, 40); }
+#ifndef ZC_MULSQ_STAGED_MIN_BYTES
+#define ZC_MULSQ_STAGED_MIN_BYTES STREAM_BYTES
+#endif
+int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, ZC_MULSQ_STAGED ? zc::k_fe_mul_stream : nullptr, a, b, o, n, 40, ZC_MULSQ_STAGED_MIN_BYTES); }
 int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
-int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40, ZC_MULSQ_STAGED ? zc::k_fe_square_stream : nullptr); }
+int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40, ZC_MULSQ_STAGED ? zc::k_fe_square_stream : nullptr, ZC_MULSQ_STAGED_MIN_BYTES); }
 
 // Montgomery's trick shares one inversion among the c consecutive elements of a lane (3 multiplications per
 // element + one inversion per lane).  c = cnt / INV_LANES_TARGET keeps that many lanes busy, capped at 64;
@@ -1381,9 +1389,9 @@ int zc_fe_inv_sqrt(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* was_s
 // ---- Scalar
 int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, zc::k_sc_add_stream, a, b, o, n, 40); }
 int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, zc::k_sc_sub_stream, a, b, o, n, 40); }
-int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, nullptr, a, b, o, n, 40); }
+int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, ZC_MULSQ_STAGED ? zc::k_sc_mul_stream : nullptr, a, b, o, n, 40, ZC_MULSQ_STAGED_MIN_BYTES); }
 int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40); }
-int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40); }
+int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40, ZC_MULSQ_STAGED ? zc::k_sc_square_stream : nullptr, ZC_MULSQ_STAGED_MIN_BYTES); }
 // S-x rows: the Scalar operations beside the default scalar-mul path
 int zc_sc_half(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_half, a, o, n, 40); }
 int zc_sc_pow(zc_ctx* c, const uint64_t* a, const uint64_t* e, uint64_t* o, size_t n) { return binop(c, zc::k_sc_pow, nullptr, a, e, o, n, 40); }

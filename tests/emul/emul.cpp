@@ -64,6 +64,19 @@ void emul_fe_square(const u64* a, u64* out, size_t n, int modl)
         else store_plain<ModP>(out + 5 * i, mont_mul<ModP>(mont_sqr<ModP>(fe_from_limbs52(x)), fe_const<ModP>(ModP::RR)));
     }
 }
+// what k_fe_mul / k_fe_square / k_sc_mul / k_sc_square run per lane: the one-pass product for canonical operands, the two
+// Montgomery passes for patterns at or above 2^TOPBIT
+void emul_mulmod(const u64* a, const u64* b, u64* prod, u64* sq, size_t n, int modl)
+{
+    for (size_t i = 0; i < n; i++) {
+        u64 x[5], y[5], r[5];
+        ld5(x, a + 5 * i); ld5(y, b + 5 * i);
+        if (modl) fe_mulmod_limbs52<ModL>(r, x, y); else fe_mulmod_limbs52<ModP>(r, x, y);
+        for (int j = 0; j < 5; j++) prod[5 * i + j] = r[j];
+        if (modl) fe_sqrmod_limbs52<ModL>(r, x); else fe_sqrmod_limbs52<ModP>(r, x);
+        for (int j = 0; j < 5; j++) sq[5 * i + j] = r[j];
+    }
+}
 // the independent-chain multiplier pair used by small launches and the MSM bucket sums
 void emul_fe_mul_square_ilp(const u64* a, const u64* b, u64* prod, u64* sq, size_t n)
 {

@@ -65,6 +65,39 @@ def test_emul_mul_square(emul, oracle):
     assert np.array_equal(out, oracle.fe_mul(a, b))
 
 
+def test_emul_one_pass_product_of_the_mul_square_kernels(emul, oracle):
+    """What k_fe_mul / k_fe_square / k_sc_mul / k_sc_square run per lane since round 5 (zc_arith.hip.h: fe_mulmod_limbs52,
+    fe_sqrmod_limbs52): for canonical operands ONE pass -- a (b 2^S), two folds by 2^261 = -(c 2^S), one conditional
+    subtraction -- instead of the reference's two Montgomery passes (field.rs:250-262, :302-315; scalar.rs likewise);
+    operands at or above 2^TOPBIT take the two-pass form.  Limb for limb the oracle's Mul / Square: random and edge
+    canonical values, everything around 2^TOPBIT and N, all-ones patterns, and raw 260-bit patterns (SURVEY A.3 item 11:
+    Mul / Square are value-correct for ANY limbs < 2^52); the checked build asserts every intermediate bound."""
+    rng = np.random.default_rng(V.SEED + 700)
+    for modl, mod, top, orc_mul, orc_sq, edge in ((0, pm.P, 252, oracle.fe_mul, oracle.fe_square, V.FE_EDGE),
+                                                  (1, pm.L, 249, oracle.sc_mul, oracle.sc_square, V.SC_EDGE)):
+        vals = V.rand_fe(3000, V.SEED + 701 + modl, mod, edge)
+        special = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (mod + 1) // 2, (1 << top) - 1, (1 << top) - 2, 1 << (top - 1), (1 << (top - 1)) - 1,
+                   (1 << top), (1 << top) + 1, mod - (1 << 60), (1 << top) - (1 << 125), (1 << 125) - 1, 1 << 125, (1 << 232) - 1, 1 << 232,
+                   (1 << 29) - 1, 1 << 29, (1 << 261) % mod, ((1 << 261) - 1) % mod]
+        special += [((1 << top) - 1) ^ (1 << i) for i in range(0, top, 7)]               # all ones with one hole
+        special += [((1 << 29 * k) - 1) % mod for k in range(1, 10)] + [(1 << 29 * k) % mod for k in range(1, 9)]
+        a = V.limbs_array(vals + special + special[::-1] + [s for s in special for _ in range(2)])
+        b = V.limbs_array(list(reversed(vals)) + special + special + [special[(i * 7 + 3) % len(special)] for i in range(2 * len(special))])
+        assert len(a) == len(b)
+        prod, sq = np.empty_like(a), np.empty_like(a)
+        emul.emul_mulmod(p(a), p(b), p(prod), p(sq), C.c_size_t(len(a)), modl)
+        assert np.array_equal(prod, orc_mul(a, b)) and np.array_equal(sq, orc_sq(a))
+        # raw patterns: any limbs < 2^52 (most of them at or above 2^TOPBIT: the two-pass branch), and patterns just below 2^TOPBIT
+        a = rng.integers(0, 1 << 52, size=(1500, 5), dtype=np.uint64)
+        b = rng.integers(0, 1 << 52, size=(1500, 5), dtype=np.uint64)
+        a[::2, 4] >>= np.uint64(52 - (top - 208))                                         # every other operand below 2^TOPBIT
+        b[::3, 4] >>= np.uint64(52 - (top - 208))
+        a[5::6, 4] = (1 << (top - 208)) - 1                                               # top limb all ones below the bound
+        prod, sq = np.empty_like(a), np.empty_like(a)
+        emul.emul_mulmod(p(a), p(b), p(prod), p(sq), C.c_size_t(len(a)), modl)
+        assert np.array_equal(prod, orc_mul(a, b)) and np.array_equal(sq, orc_sq(a))
+
+
 def test_emul_invert_sqrt_ratio(emul, oracle):
     a = V.limbs_array(V.rand_fe(200, V.SEED + 3))
     out, ok = np.empty_like(a), np.empty(len(a), dtype=np.uint8)
