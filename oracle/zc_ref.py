@@ -14,6 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libzc_ref.so")
+# tests/test_sanitizers.py: load another build of the same file (`make -C oracle asan`) instead -- never rebuilt here
+_SO_OVERRIDE = os.environ.get("ZC_REF_SO")
 
 
 BASE_FLAGS = "-O3 -fPIC -std=c11 -Wall -Wextra"
@@ -122,8 +124,11 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()                                                  # rebuilds when the .so was made for another CPU model
-        _lib = C.CDLL(_SO)
+        if _SO_OVERRIDE:
+            _lib = C.CDLL(_SO_OVERRIDE)
+        else:
+            build()                                              # rebuilds when the .so was made for another CPU model
+            _lib = C.CDLL(_SO)
     return _lib
 
 
