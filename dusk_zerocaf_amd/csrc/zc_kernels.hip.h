@@ -1469,17 +1469,6 @@ ZC_KERNEL void k_ed_fold_pairs(const u64* in, u64* out, size_t n_in)
     else pt_store(out + 20 * i, a);
 }
 
-// ((p0 + p1) + p2) + ... in index order with the unified addition (edwards.rs:465-489), one
-// launch: the exchange step of a sharded MSM folds the gathered per-rank partials with this, so
-// every rank ends with identical limbs.  `count` is small (one point per GPU); a single lane on
-// the independent-chain multiplier.  `extra` (optional) is added last.
-ZC_KERNEL void k_ed_fold_ordered(const u64* parts, size_t count, const u64* extra, u64* out)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    pt acc = count ? pt_load(parts) : pt_identity();
-    for (size_t i = 1; i < count; i++) acc = pt_add<true>(acc, pt_load(parts + 20 * i));
-    if (extra) acc = pt_add<true>(acc, pt_load(extra));
-    pt_store(out, acc);
-}
+// (k_ed_fold_ordered, the rank-order fold of the MSM exchange: zc_quad.hip.h)
 
 }  // namespace zc
