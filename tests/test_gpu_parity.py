@@ -364,6 +364,42 @@ def test_bytes_codecs_bulk(eng, oracle):
     assert eq(eng.fe_to_bytes(a), oracle.fe_to_bytes(a))
 
 
+@pytest.mark.parametrize("n", [4096, 4097 + 300, 20001])
+def test_point_add_sub_double_staged_records(eng, oracle, n):
+    """From 2^12 points on, add / sub / double move their 160-byte records through LDS (k_ed_*_staged: coalesced 16-byte
+    accesses, one operand after the other through one buffer); below, and for arrays that are not 16-byte aligned, every
+    lane reads its own record.  Both forms, full and ragged last workgroups, host and device pointers: limb for limb the
+    oracle's Add / Sub / Double (edwards.rs:465-489, :503-531, :579-592), canonical edge coordinates included."""
+    import torch
+    P = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 600 + n, bits=249))
+    Q = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 601 + n, bits=249))
+    P[0] = V.IDENT_ROW
+    Q[1] = V.IDENT_ROW
+    Q[2] = P[2]
+    Q[3] = oracle.ed_neg(P[3:4])[0]
+    edge = [pm.limbs(pm.P - 1), pm.limbs(pm.P - 2), [0] * 5, [1, 0, 0, 0, 0], pm.limbs((pm.P + 1) // 2), pm.limbs((1 << 252) - 1)]
+    rng = np.random.default_rng(V.SEED + 602)
+    for row in (5, 255, 256, n - 1):                              # canonical edge coordinates (off-curve: garbage in, the reference's garbage out)
+        P[row] = sum([edge[rng.integers(len(edge))] for _ in range(4)], [])
+        Q[row - 1] = sum([edge[rng.integers(len(edge))] for _ in range(4)], [])
+    wadd, wsub, wdbl = oracle.ed_add(P, Q), oracle.ed_sub(P, Q), oracle.ed_double(P)
+    assert eq(eng.ed_add(P, Q), wadd) and eq(eng.ed_sub(P, Q), wsub) and eq(eng.ed_double(P), wdbl)
+    dP, dQ = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, Q))
+    for got, want in ((eng.ed_add(dP, dQ), wadd), (eng.ed_sub(dP, dQ), wsub), (eng.ed_double(dP), wdbl)):
+        torch.cuda.synchronize()
+        assert eq(got.cpu().numpy().view(np.uint64), want)
+    # arrays that start 8 bytes off a 16-byte boundary: the per-lane kernels
+    flatP = torch.empty(n * 20 + 1, dtype=torch.int64, device="cuda")
+    flatQ = torch.empty(n * 20 + 1, dtype=torch.int64, device="cuda")
+    oP, oQ = flatP[1:].view(n, 20), flatQ[1:].view(n, 20)
+    assert oP.data_ptr() % 16 == 8
+    oP.copy_(dP)
+    oQ.copy_(dQ)
+    for got, want in ((eng.ed_add(oP, oQ), wadd), (eng.ed_sub(oP, dQ), wsub), (eng.ed_double(oP), wdbl)):
+        torch.cuda.synchronize()
+        assert eq(got.cpu().numpy().view(np.uint64), want)
+
+
 @pytest.mark.parametrize("n", [1, 63, 300])
 def test_point_ops_bulk(eng, oracle, n):
     P = V.base_multiples(oracle, n, V.SEED + 30 + n)
