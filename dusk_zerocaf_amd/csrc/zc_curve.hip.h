@@ -546,9 +546,40 @@ ZC_DI pt pt_add(const pt& p, const pt& q)
 }
 // The stand-alone point kernels (k_ed_add / sub / double / coset4) skip the Montgomery conversions: with PLAIN
 // canonical coordinates and the constant d in Montgomery form, every first-level product of pt_add comes out
-// with a factor 1/R (M, P, D directly; C = (dR * T1 / R) * T2 / R), the linear steps keep it, and the four
-// outputs carry 1/R^3 -- one multiplication by R^4 per coordinate returns the plain value.  13 multiplications
-// per addition instead of 8 (into the domain) + 9 + 4 (out of it); the canonical results are the same limbs.
+// with a factor 1/R (M, P, D directly; C = (dR * T1 / R) * T2 / R) and the linear steps keep it.  The four outputs are
+// the products E F, G H, F G, E H: E and G each stand in two of them, one on every output, so scaling those TWO values by
+// R^4 (one multiplication each) makes all four outputs plain: (E R^4 / R) F / R = E_true F_true.  11 multiplications per
+// addition (rounds 2-4: 13, one multiplication by R^4 per OUTPUT; before that 8 into the domain + 9 + 4 out of it); the
+// canonical results are the same limbs.
+template <bool ILP = false>
+ZC_DI pt pt_add_plain(const pt& p, const pt& q)         // plain R-class coordinates in, plain R-class coordinates out
+{
+    auto fp_mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
+    const fe M = fp_mul(fp_sub(p.Y, p.X), fp_sub(q.Y, q.X));
+    const fe P = fp_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
+    const fe C = fp_mul(fp_mul(fe_const<FP>(ModP::D_M), p.T), q.T);
+    const fe D = fp_mul(p.Z, q.Z);
+    const fe E = fe_sub_half<FP>(P, M);
+    const fe H = fp_sub(P, E);
+    const fe F = fp_sub(D, C);
+    const fe r4 = fe_const<FP>(ModP::R4);
+    const fe Es = fp_mul(E, r4);                          // E_true R^2
+    const fe Gs = fp_mul(fe_add(D, C), r4);               // G_true R^2
+    pt r;
+    r.X = fp_mul(Es, F);
+    r.Y = fp_mul(Gs, H);
+    r.Z = fp_mul(F, Gs);
+    r.T = fp_mul(Es, H);
+    return r;
+}
+ZC_DI void pt_store_plain(u64* __restrict__ o, const pt& p)                   // plain R-class coordinates -> canonical limbs
+{
+    u64 l[5];
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(p.X))); store5(o, l);
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(p.Y))); store5(o + 5, l);
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(p.Z))); store5(o + 10, l);
+    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(p.T))); store5(o + 15, l);
+}
 // A plain coordinate as it comes from memory.  The plain-domain formulas need it R-class (< 3p: fe_sub's subtrahend);
 // canonical limbs are.  Any other 5 x 52-bit pattern (value up to 2^260) is first brought there -- into the Montgomery
 // domain and back, two multiplications -- on a branch canonical data never takes (top limb < 2^44 means value < 2^252),
@@ -569,15 +600,6 @@ ZC_DI pt pt_load_plain(const u64* __restrict__ p)
     r.Z = fe_load_plain(p + 10);
     r.T = fe_load_plain(p + 15);
     return r;
-}
-ZC_DI void pt_store_plain_r3(u64* __restrict__ o, const pt& p)           // p = (true value) / R^3 per coordinate
-{
-    const fe r4 = fe_const<FP>(ModP::R4);
-    u64 l[5];
-    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.X, r4)))); store5(o, l);
-    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.Y, r4)))); store5(o + 5, l);
-    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.Z, r4)))); store5(o + 10, l);
-    fe_to_limbs52(l, fe_cond_sub_n<FP>(fe_cond_sub_n<FP>(mont_mul<FP>(p.T, r4)))); store5(o + 15, l);
 }
 // The scalar-multiplication loop keeps its two points as (Y-X, Y+X, Z, T): the unified addition
 // consumes exactly these combinations of BOTH operands, so forming them once per result instead

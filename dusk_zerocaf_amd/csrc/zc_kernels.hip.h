@@ -483,21 +483,21 @@ ZC_KERNEL void k_ed_add(const u64* p, const u64* q, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
-    pt_store_plain_r3(out + 20 * i, pt_add(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)));   // plain domain: zc_curve.hip.h
+    pt_store_plain(out + 20 * i, pt_add_plain(pt_load_plain(p + 20 * i), pt_load_plain(q + 20 * i)));   // plain domain: zc_curve.hip.h
 }
 ZC_KERNEL void k_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
     // edwards.rs:503-531: add of the negated rhs with H = B - a*A == B + A (a = -1): same values
-    pt_store_plain_r3(out + 20 * i, pt_add(pt_load_plain(p + 20 * i), pt_neg(pt_load_plain(q + 20 * i))));
+    pt_store_plain(out + 20 * i, pt_add_plain(pt_load_plain(p + 20 * i), pt_neg(pt_load_plain(q + 20 * i))));
 }
 ZC_KERNEL void k_ed_double(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
     const pt a = pt_load_plain(p + 20 * i);
-    pt_store_plain_r3(out + 20 * i, pt_add(a, a));
+    pt_store_plain(out + 20 * i, pt_add_plain(a, a));
 }
 // The same three with the records staged through LDS (16-byte aligned arrays).  A lane's 160-byte record is strided in
 // memory: read per lane it takes twenty 8-byte loads that each touch a cache line of their own, the wave's working set
@@ -534,9 +534,9 @@ ZC_DI void ed_binop_staged(const u64* p, const u64* q, u64* out, size_t n)
     } else {
         b = a;
     }
-    const pt r = pt_add(a, b);
+    const pt r = pt_add_plain(a, b);
     __syncthreads();                                         // ... and then the results
-    if (t < cnt) pt_store_plain_r3(sp + 20 * t, r);
+    if (t < cnt) pt_store_plain(sp + 20 * t, r);
     __syncthreads();
     u64x2* go = reinterpret_cast<u64x2*>(out + 20 * base);
     for (int v = t; v < cnt * 10; v += B) go[v] = lv[v];
@@ -545,6 +545,34 @@ ZC_DI void ed_binop_staged(const u64* p, const u64* q, u64* out, size_t n)
 ZC_KERNEL_EDS void k_ed_add_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<0>(p, q, out, n); }
 ZC_KERNEL_EDS void k_ed_sub_staged(const u64* p, const u64* q, u64* out, size_t n) { ed_binop_staged<1>(p, q, out, n); }
 ZC_KERNEL_EDS void k_ed_double_staged(const u64* p, u64* out, size_t n) { ed_binop_staged<2>(p, nullptr, out, n); }
+// Neg with staged records: the workgroup's records pass through LDS once, X and T are negated in place there (the
+// reference's radix-2^52 borrow chain, as k_ed_neg below), Y and Z ride along.
+ZC_KERNEL_EDS void k_ed_neg_staged(const u64* p, u64* out, size_t n)
+{
+    constexpr int B = ED_STAGED_BLOCK;
+    __shared__ __attribute__((aligned(16))) u64 sp[B * 20];
+    const size_t base = (size_t)blockIdx.x * B;
+    const int cnt = (int)((n - base < (size_t)B) ? (n - base) : (size_t)B);
+    const int t = threadIdx.x;
+    const u64x2* gp = reinterpret_cast<const u64x2*>(p + 20 * base);
+    u64x2* lv = reinterpret_cast<u64x2*>(sp);
+    for (int v = t; v < cnt * 10; v += B) lv[v] = gp[v];
+    __syncthreads();
+    if (t < cnt) {
+        u64 m[5], X[5], T[5], nx[5], nt[5];
+        const u64 z[5] = {0, 0, 0, 0, 0};
+        limbs52_of_modulus<ModP>(m);
+        load5(X, sp + 20 * t);
+        load5(T, sp + 20 * t + 15);
+        sub52(nx, z, X, m);
+        sub52(nt, z, T, m);
+        store5(sp + 20 * t, nx);
+        store5(sp + 20 * t + 15, nt);
+    }
+    __syncthreads();
+    u64x2* go = reinterpret_cast<u64x2*>(out + 20 * base);
+    for (int v = t; v < cnt * 10; v += B) go[v] = lv[v];
+}
 ZC_KERNEL void k_ed_neg(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();
@@ -1381,7 +1409,7 @@ ZC_KERNEL void k_ed_coset4(const u64* p, u64* out4, size_t n)
         C.Z = fe_zero();
         C.Z.v[0] = 1;
         C.T = fe_zero();
-        pt_store_plain_r3(out4 + 80 * i + 20 * (j + 1), pt_add(P, C));
+        pt_store_plain(out4 + 80 * i + 20 * (j + 1), pt_add_plain(P, C));
     }
 }
 ZC_KERNEL void k_proj_neg(const u64* p, u64* out, size_t n)                          // edwards.rs:787-807: (-X, Y, Z)

@@ -1437,7 +1437,7 @@ constexpr size_t ED_STAGED_MIN_BYTES = (size_t)160 * 3 << 12;
 int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, zc::k_ed_add_staged, p, q, o, n, 160, ED_STAGED_MIN_BYTES); }
 int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, zc::k_ed_sub_staged, p, q, o, n, 160, ED_STAGED_MIN_BYTES); }
 int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160, zc::k_ed_double_staged, ED_STAGED_MIN_BYTES); }
-int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160); }
+int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160, zc::k_ed_neg_staged, ED_STAGED_MIN_BYTES); }
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {

@@ -365,8 +365,8 @@ def test_bytes_codecs_bulk(eng, oracle):
 
 
 @pytest.mark.parametrize("n", [4096, 4097 + 300, 20001])
-def test_point_add_sub_double_staged_records(eng, oracle, n):
-    """From 2^12 points on, add / sub / double move their 160-byte records through LDS (k_ed_*_staged: coalesced 16-byte
+def test_point_add_sub_double_neg_staged_records(eng, oracle, n):
+    """From 2^12 points on, add / sub / double / neg move their 160-byte records through LDS (k_ed_*_staged: coalesced 16-byte
     accesses, one operand after the other through one buffer); below, and for arrays that are not 16-byte aligned, every
     lane reads its own record.  Both forms, full and ragged last workgroups, host and device pointers: limb for limb the
     oracle's Add / Sub / Double (edwards.rs:465-489, :503-531, :579-592), canonical edge coordinates included."""
@@ -382,10 +382,10 @@ def test_point_add_sub_double_staged_records(eng, oracle, n):
     for row in (5, 255, 256, n - 1):                              # canonical edge coordinates (off-curve: garbage in, the reference's garbage out)
         P[row] = sum([edge[rng.integers(len(edge))] for _ in range(4)], [])
         Q[row - 1] = sum([edge[rng.integers(len(edge))] for _ in range(4)], [])
-    wadd, wsub, wdbl = oracle.ed_add(P, Q), oracle.ed_sub(P, Q), oracle.ed_double(P)
-    assert eq(eng.ed_add(P, Q), wadd) and eq(eng.ed_sub(P, Q), wsub) and eq(eng.ed_double(P), wdbl)
+    wadd, wsub, wdbl, wneg = oracle.ed_add(P, Q), oracle.ed_sub(P, Q), oracle.ed_double(P), oracle.ed_neg(Q)
+    assert eq(eng.ed_add(P, Q), wadd) and eq(eng.ed_sub(P, Q), wsub) and eq(eng.ed_double(P), wdbl) and eq(eng.ed_neg(Q), wneg)
     dP, dQ = (torch.from_numpy(a.view(np.int64)).cuda() for a in (P, Q))
-    for got, want in ((eng.ed_add(dP, dQ), wadd), (eng.ed_sub(dP, dQ), wsub), (eng.ed_double(dP), wdbl)):
+    for got, want in ((eng.ed_add(dP, dQ), wadd), (eng.ed_sub(dP, dQ), wsub), (eng.ed_double(dP), wdbl), (eng.ed_neg(dQ), wneg)):
         torch.cuda.synchronize()
         assert eq(got.cpu().numpy().view(np.uint64), want)
     # arrays that start 8 bytes off a 16-byte boundary: the per-lane kernels
@@ -395,7 +395,7 @@ def test_point_add_sub_double_staged_records(eng, oracle, n):
     assert oP.data_ptr() % 16 == 8
     oP.copy_(dP)
     oQ.copy_(dQ)
-    for got, want in ((eng.ed_add(oP, oQ), wadd), (eng.ed_sub(oP, dQ), wsub), (eng.ed_double(oP), wdbl)):
+    for got, want in ((eng.ed_add(oP, oQ), wadd), (eng.ed_sub(oP, dQ), wsub), (eng.ed_double(oP), wdbl), (eng.ed_neg(oQ), wneg)):
         torch.cuda.synchronize()
         assert eq(got.cpu().numpy().view(np.uint64), want)
 
