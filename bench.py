@@ -431,56 +431,86 @@ def roofline_for(env, run, kern_avg_s):
     return roofline
 
 
+SAMPLE_SEED = 0x5A3D
+
+
+def spread_sample(n, m, seed=SAMPLE_SEED):
+    """Which m of a batch's n units the oracle recomputes: the first m/4, the last m/4 (the ragged last workgroup, the tail
+    of a persistent kernel's schedule) and a seeded, jittered stride through everything between them (one unit out of every
+    `step` consecutive ones, its place inside the stretch drawn at random: every residue modulo the wave, workgroup and tile
+    sizes occurs).  Sorted, no duplicates; all n when m >= n."""
+    if m >= n:
+        return np.arange(n, dtype=np.int64)
+    h = m // 4
+    mid = m - 2 * h
+    step = (n - 2 * h) // mid
+    rng = np.random.default_rng(seed ^ n)
+    middle = h + step * np.arange(mid, dtype=np.int64) + rng.integers(0, step, size=mid)
+    return np.concatenate([np.arange(h, dtype=np.int64), middle, np.arange(n - h, n, dtype=np.int64)])
+
+
+def take_rows(env, t, idx):
+    """rows idx of a device tensor, on the host"""
+    return t.index_select(0, env.torch.from_numpy(idx).to(t.device)).cpu().numpy()
+
+
 def cpu_leg(env, run, sample):
     """The same operation on the host cores with the oracle (reference-shaped C restatement), on a
-    bounded sample taken from the head of the rank's own inputs.  Returns (rate, cores, seconds, units,
-    oracle results for the head of the batch) -- the results are the parity spot check."""
+    bounded sample of the rank's own inputs spread over the whole batch (spread_sample: head, tail and a seeded
+    stride through the middle).  Returns (rate, cores, seconds, units, oracle results for the sampled units,
+    their indices) -- the results are the parity spot check."""
     from oracle import zc_ref
     zc_ref.build()
     zc_ref.lib()
     wl, n, data = run["wl"], run["n"], run["data"]
     cores = zc_ref.host_threads()
     m = min(sample, n)
-    host = lambda t: np.ascontiguousarray(t[:m].cpu().numpy()).view(np.uint64)
+    idx = spread_sample(n, m)
+    host = lambda t: np.ascontiguousarray(take_rows(env, t, idx)).view(np.uint64)
+    pick = lambda a: np.ascontiguousarray(a[idx])
     t0 = time.perf_counter()
     if wl == "fe_mul":
-        a, b = data["host"]
+        a, b = pick(data["host"][0]), pick(data["host"][1])
+        t0 = time.perf_counter()
         reps = max(1, sample // m)
         want = None
         for _ in range(reps):
-            want = zc_ref.mt(zc_ref.fe_mul, a[:m], b[:m])
+            want = zc_ref.mt(zc_ref.fe_mul, a, b)
         m *= reps
     elif wl == "fe_invert":
-        want = zc_ref.mt(zc_ref.fe_invert, data["host"][0][:m])
+        a = pick(data["host"][0])
+        t0 = time.perf_counter()
+        want = zc_ref.mt(zc_ref.fe_invert, a)
     elif wl == "scalar_mul":
-        want = zc_ref.mt(zc_ref.ed_scalar_mul, host(data["P"]), data["host_K"][:m])
+        want = zc_ref.mt(zc_ref.ed_scalar_mul, host(data["P"]), pick(data["host_K"]))
     elif wl == "ristretto":
-        want = zc_ref.mt(zc_ref.ris_roundtrip_mul, data["enc"][:m].cpu().numpy(), data["host_K"][:m])
+        want = zc_ref.mt(zc_ref.ris_roundtrip_mul, np.ascontiguousarray(take_rows(env, data["enc"], idx)), pick(data["host_K"]))
     elif wl == "ecdh":
         # the reference's ecdh_double_add: key pairs with double_and_add on the basepoint, then the two shared secrets
-        a, b = data["host"][0][:m], data["host"][1][:m]
+        a, b = pick(data["host"][0]), pick(data["host"][1])
         base = np.tile(np.array(BASEPOINT_LIMBS, dtype=np.uint64), (m, 1))
         pa = zc_ref.mt(zc_ref.ed_scalar_mul, base, a)
         pb = zc_ref.mt(zc_ref.ed_scalar_mul, base, b)
         s1 = zc_ref.mt(zc_ref.ed_scalar_mul, pb, a)
         s2 = zc_ref.mt(zc_ref.ed_scalar_mul, pa, b)
         want = (pa, pb, s1, s2)
-    else:                                           # msm: the reference's own sum of Mul<Scalar> over the sample
-        want = zc_ref.msm_naive_mt(host(data["P"]), data["host_K"][:m])
+    else:                                           # msm: the reference's own sum of Mul<Scalar> over the sampled pairs
+        want = zc_ref.msm_naive_mt(host(data["P"]), pick(data["host_K"]))
     dt = time.perf_counter() - t0
-    return m / dt, cores, dt, m, want
+    return m / dt, cores, dt, m, want, idx
 
 
 def check_and_baseline(env, run, sample, baseline_leg, msm_fold_ok=None):
-    """Oracle results for the head of the batch against the GPU's (a mismatch aborts the run); the CPU rate beside it."""
+    """Oracle results for a sample spread over the whole batch (spread_sample) against the GPU's outputs at the same places
+    (a mismatch aborts the run); the CPU rate beside it."""
     from oracle import zc_ref
     torch, eng = env.torch, env.eng
     wl, n, data, st, mode = run["wl"], run["n"], run["data"], run["st"], run["mode"]
-    v, cores, secs, total, want = cpu_leg(env, run, sample)
+    v, cores, secs, total, want, idx = cpu_leg(env, run, sample)
     torch.cuda.synchronize()
+    rows = lambda t: take_rows(env, t, idx)                  # the GPU's outputs for the sampled units
     if wl == "scalar_mul":
-        k = min(len(want), n)
-        got = st["out"][:k].cpu().numpy().view(np.uint64)
+        got = rows(st["out"]).view(np.uint64)
         if mode == "fast":                           # same group element: compare encodings
             enc = lambda pts: eng.ed_compress(torch.from_numpy(np.ascontiguousarray(pts).view(np.int64)).cuda())[0].cpu().numpy()
             checked = bool(np.array_equal(enc(got), enc(want)))
@@ -489,32 +519,30 @@ def check_and_baseline(env, run, sample, baseline_leg, msm_fold_ok=None):
     elif wl == "fe_mul":
         got = run["step"]()
         torch.cuda.synchronize()
-        checked = bool(np.array_equal(got[:len(want)].cpu().numpy().view(np.uint64), want))
+        checked = bool(np.array_equal(rows(got).view(np.uint64), want))
     elif wl == "fe_invert":
         got, gok = run["step"]()
         torch.cuda.synchronize()
-        k = len(want[0])
-        checked = bool(np.array_equal(got[:k].cpu().numpy().view(np.uint64), want[0]) and np.array_equal(gok[:k].cpu().numpy(), want[1]))
+        checked = bool(np.array_equal(rows(got).view(np.uint64), want[0]) and np.array_equal(rows(gok), want[1]))
     elif wl == "ristretto":
         wout, wok = want
-        k = len(wout)
-        checked = bool(np.array_equal(st["out"][:k].cpu().numpy(), wout) and np.array_equal(st["ok"][:k].cpu().numpy(), wok))
+        checked = bool(np.array_equal(rows(st["out"]), wout) and np.array_equal(rows(st["ok"]), wok))
     elif wl == "ecdh":
         pa, pb, s1, s2 = want
-        k = len(pa)
         if run["ecdh"] == "wire":
             # the bytes on the wire are the reference's: compress() of its own key pairs and shared secrets; and EVERY exchange agrees
-            checked = bool(np.array_equal(st["A"][:k].cpu().numpy(), zc_ref.ris_compress(pa)) and np.array_equal(st["Bp"][:k].cpu().numpy(), zc_ref.ris_compress(pb))
-                           and np.array_equal(st["S"][:k].cpu().numpy(), zc_ref.ris_compress(s1)) and np.array_equal(st["Sp"][:k].cpu().numpy(), zc_ref.ris_compress(s2))
+            checked = bool(np.array_equal(rows(st["A"]), zc_ref.ris_compress(pa)) and np.array_equal(rows(st["Bp"]), zc_ref.ris_compress(pb))
+                           and np.array_equal(rows(st["S"]), zc_ref.ris_compress(s1)) and np.array_equal(rows(st["Sp"]), zc_ref.ris_compress(s2))
                            and bool(torch.equal(st["S"], st["Sp"])) and bool(st["ok1"].all()) and bool(st["ok2"].all()))
         else:
-            g = lambda key: st[key][:k].cpu().numpy().view(np.uint64)
+            g = lambda key: rows(st[key]).view(np.uint64)
             checked = bool(np.array_equal(g("A"), pa) and np.array_equal(g("Bp"), pb) and np.array_equal(g("S"), s1) and np.array_equal(g("Sp"), s2)
                            and bool(eng.ris_eq(st["S"], st["Sp"]).all()))
     else:
-        # MSM: the GPU sum over the first `total` pairs against the oracle's sum of the same pairs,
-        # compared as canonical encodings (zc_msm contract: a group element)
-        sub = eng.msm(data["P"][:total], data["K"][:total])
+        # MSM: the GPU sum over the sampled pairs (head, tail and the seeded stride, gathered) against the oracle's sum of
+        # the same pairs, compared as canonical encodings (zc_msm contract: a group element)
+        it = torch.from_numpy(idx).to(data["P"].device)
+        sub = eng.msm(data["P"].index_select(0, it).contiguous(), data["K"].index_select(0, it).contiguous())
         checked = bool(np.array_equal(zc_ref.ed_compress(sub)[0], zc_ref.ed_compress(want)[0]) and zc_ref.ed_eq(sub, want)[0] == 1)
         if total == n and env.world == 1:
             checked = checked and bool(np.array_equal(zc_ref.ed_compress(st["result"])[0], zc_ref.ed_compress(want)[0]))
@@ -558,7 +586,8 @@ def check_and_baseline(env, run, sample, baseline_leg, msm_fold_ok=None):
     cpu = {"value": round(v, 1), "unit": WORKLOADS[wl]["unit"], "cores": cores, "kind": "port",
            "value_per_core": round(v / cores, 1), "value_single_core": single["value"] if single else round(v, 1),
            "single_core_sample_units": single["units"] if single else total, "cpu_model": model,
-           "sample": "%d units from the head of the same seeded workload, %d threads, %.1f s wall (%.0f s of CPU work): %s; C "
+           "sample": "%d units of the same seeded workload spread over the whole batch (first quarter of the sample from the head, last quarter "
+                     "from the tail, the rest a seeded jittered stride through the middle), %d threads, %.1f s wall (%.0f s of CPU work): %s; C "
                      "restatement of zerocaf's u64 backend (oracle/zc_ref.c, gcc %s, built on this host), not the Rust binary"
                      % (total, cores, secs, secs * cores, what, zc_ref.build_flags())}
     return checked, cpu

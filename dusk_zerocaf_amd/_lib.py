@@ -168,13 +168,22 @@ def load_test_hooks() -> C.CDLL:
     global _test_lib
     if _test_lib is None:
         if not os.path.exists(TEST_LIB_PATH):
-            raise ZerocafHipError("libzerocaf_hip_test.so is missing: build it with `python -m dusk_zerocaf_amd.build --test-hooks`")
+            raise ZerocafHipError("libzerocaf_hip_test.so is missing: build it with `python -m dusk_zerocaf_amd.build`")
         _share_hip_runtime_with_torch()
-        _test_lib = _bind(TEST_LIB_PATH)
+        lib = _bind(TEST_LIB_PATH)
+        # the twin must come from the very sources the product was built from (both embed their sha256): after a source
+        # edit and a product-only rebuild the GPU tests would otherwise run a stale binary -- possibly with another ABI
+        src = lambda l: l.zc_version().decode().rsplit("src:", 1)[-1]
+        if os.path.exists(LIB_PATH) and src(lib) != src(load()):
+            raise ZerocafHipError("libzerocaf_hip_test.so (src:%s) was not built from the product's sources (src:%s): "
+                                  "rebuild both with `python -m dusk_zerocaf_amd.build`" % (src(lib)[:12], src(load())[:12]))
+        _test_lib = lib
         _test_lib.zc_test_msm_sort.argtypes = [_ctx, _u64p, _n, C.c_int, C.c_void_p]
         _test_lib.zc_test_msm_sort.restype = C.c_int
         _test_lib.zc_test_odd_table.argtypes = [_ctx, C.c_void_p]
         _test_lib.zc_test_odd_table.restype = C.c_int
+        _test_lib.zc_test_staged_launches.argtypes = [_ctx]
+        _test_lib.zc_test_staged_launches.restype = C.c_longlong
     return _test_lib
 
 

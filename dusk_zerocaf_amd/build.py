@@ -65,8 +65,8 @@ def _stale(lib: str) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, test_hooks: bool = False) -> str:
-    """libzerocaf_hip.so (the product) and, with test_hooks=True (the test tier and __graft_entry__.build() ask for it;
-    `--test-hooks` on the command line), libzerocaf_hip_test.so: the same sources with -DZC_TEST_HOOKS -- the fault
+    """libzerocaf_hip.so (the product) and, with test_hooks=True (the test tier, __graft_entry__.build() and the command
+    line unless `--product-only`), libzerocaf_hip_test.so: the same sources with -DZC_TEST_HOOKS -- the fault
     injection knobs, the path forcers and the sort-stage hook the GPU test tier uses; never loaded by the product
     path.  The two hipcc runs go side by side."""
     build_ubench(force, verbose)
@@ -104,4 +104,5 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
         sys.exit(0)
-    print(build(force="--force" in sys.argv, verbose=True, test_hooks="--test-hooks" in sys.argv))
+    # both libraries by default (the test tier refuses a twin built from other sources); --product-only skips the twin
+    print(build(force="--force" in sys.argv, verbose=True, test_hooks="--product-only" not in sys.argv))

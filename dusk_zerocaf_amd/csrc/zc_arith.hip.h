@@ -491,6 +491,18 @@ ZC_DI void fe_to_limbs52(u64 (&l)[5], const fe& c)
 #ifndef ZC_MULSQ_ONEPASS
 #define ZC_MULSQ_ONEPASS 1      // 0: A/B build on the two Montgomery passes of rounds 1-4
 #endif
+// The product form is chosen per WAVE, not per lane: if any active lane holds an operand at or above 2^TOPBIT the whole wave
+// takes the two-pass form (correct for every pattern), otherwise the one-pass form.  A per-lane branch makes a mixed wave
+// execute both bodies one after the other (raw 252-bit scalar patterns: 7 lanes of 8 are "non-canonical" -- 10 % slower
+// than round 4); a uniform branch executes one.  On the host (tests/emul) a "wave" is the one element.
+#ifndef ZC_MULSQ_WAVE_UNIFORM
+#define ZC_MULSQ_WAVE_UNIFORM 1   // 0: A/B build with the per-lane branch of round 5
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+ZC_DI bool mulsq_wave_any(bool p) { return ZC_MULSQ_WAVE_UNIFORM ? __builtin_amdgcn_ballot_w64(p) != 0 : p; }
+#else
+ZC_DI bool mulsq_wave_any(bool p) { return p; }
+#endif
 // value * 2^sh of five 52-bit limbs -> nine normalized 29-bit limbs (value < 2^(261 - sh))
 ZC_DI fe fe_from_limbs52_shl(const u64 (&l)[5], const int sh)
 {
@@ -598,7 +610,7 @@ template <class F>
 ZC_DI void fe_mulmod_limbs52(u64 (&r)[5], const u64 (&xa)[5], const u64 (&xb)[5])
 {
     constexpr int TOP = F::TOPBIT - 208;                                   // bits of limb 4 below 2^TOPBIT
-    if (!ZC_MULSQ_ONEPASS || (((xa[4] | xb[4]) & M52) >> TOP) != 0) {     // an operand at or above 2^TOPBIT: (a R) b / R as before
+    if (!ZC_MULSQ_ONEPASS || mulsq_wave_any((((xa[4] | xb[4]) & M52) >> TOP) != 0)) {     // an operand (of the wave) at or above 2^TOPBIT: (a R) b / R as before
         const fe am = mont_to<F>(fe_from_limbs52(xa));
         fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(mont_mul<F>(am, fe_from_limbs52(xb)))));
         return;
@@ -625,7 +637,7 @@ template <class F>
 ZC_DI void fe_sqrmod_limbs52(u64 (&r)[5], const u64 (&xa)[5])
 {
     constexpr int TOP = F::TOPBIT - 208, ODD = F::PSHIFT & 1;
-    if (!ZC_MULSQ_ONEPASS || ((xa[4] & M52) >> TOP) != 0) {
+    if (!ZC_MULSQ_ONEPASS || mulsq_wave_any(((xa[4] & M52) >> TOP) != 0)) {
         const fe a = fe_from_limbs52(xa);                     // any 260-bit pattern: (a R) a / R, within mont_mul's bounds
         fe_to_limbs52(r, fe_cond_sub_n<F>(fe_cond_sub_n<F>(mont_mul<F>(mont_to<F>(a), a))));
         return;

@@ -919,8 +919,9 @@ ZC_DI ring_table ring_acquire(u32* __restrict__ table, u32* __restrict__ state, 
             if (f == RING_SLOT_DEAD || ++spins > spin_limit) {
                 // give up: flag the device, take no slot (the caller writes poison and ends), and leave the slot marked DEAD so
                 // that the generations queued behind this one give up at their first poll instead of spinning ~4 s each (a
-                // launch of 2^24 lanes has 64 generations per slot).  Should the late holder release after all, its store
-                // puts the slot back in service for whoever comes next.
+                // launch of 2^24 lanes has 64 generations per slot).  ring_release publishes with an atomic MAX, so a late
+                // holder's release cannot bring a dead slot back: it stays DEAD (0xFFFFFFFF is the maximum) until the host
+                // zeroes the ring state before the next launch, and the error word is already set.
                 if (lane == 0) {
                     u32* err = *reinterpret_cast<u32* const*>(state + RING_ERR_WORD);
                     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -937,7 +938,8 @@ ZC_DI void ring_release(u32* __restrict__ state, const u32* __restrict__ hold)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every table read of every lane has returned
     if (lane_id_fresh() == 0) {
         const u32 h = *hold;
-        __hip_atomic_store(state + (h & 0x1FFFu), h >> 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // generations only grow, so MAX is a store for a live slot -- and leaves RING_SLOT_DEAD in place
+        __hip_atomic_fetch_max(state + (h & 0x1FFFu), h >> 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 ZC_KERNEL_3W void k_ed_scalar_mul_fast(const u64* p, const u64* k, u32 k_stride, u64* out, u32* table, u32* ring, u32 ring_slots, u32 n)

@@ -62,9 +62,6 @@
 #ifndef ZC_MSM_REC_STRIDE
 #define ZC_MSM_REC_STRIDE 128        // stride of the 96-byte affine records: 128 = one per cache line, 96 = packed
 #endif
-#ifndef ZC_MSM_SORT_PER_GROUP
-#define ZC_MSM_SORT_PER_GROUP 0      // 1: every window group sorted on its own, the lower groups' sorts under the top group's bucket sums
-#endif                               // (round 5: measured, not taken -- the sorts cost the bucket sums what they save in front)
 static_assert(ZC_MSM_REC_STRIDE == 96 || ZC_MSM_REC_STRIDE == 128, "ZC_MSM_REC_STRIDE");
 #ifndef ZC_MSM_ACC_ILP
 #define ZC_MSM_ACC_ILP false   // bucket sums on the column-ordered multiplier: with fixed-length runs every wave has
@@ -341,11 +338,9 @@ ZC_DI void msm_tail_priority() { __builtin_amdgcn_s_setprio(3); }
 // the run [*range_lo + j T, *range_lo + (j + 1) T) cut at *range_end (nullptr: the whole list [0, len)); the host sizes the
 // launch for the longest the part can be, lanes behind its end idle.  The neighbours a lane looks at for its open ends may
 // lie in another group (another window: another key).  `sj`: the lane's number in the edge arrays (groups share them).
-// `range_base`: where the positions *range_lo / *range_end count from -- 0 when one sort covers all windows (the scan table
-// then holds global positions), the start of the group's own part of the list when every group is sorted on its own.
 template <bool AFFINE>
 ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict__ recs, u32 len, u32 T, u32 nbuckets,
-                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 range_base, u32 j, u32 sj, u32 rec_words)
+                         u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 j, u32 sj, u32 rec_words)
 {
     constexpr int PIECES = AFFINE ? 6 : 8;                     // 16-byte pieces of a cached record
     __shared__ uint4 stage[PIECES * MSM_RUN_BLOCK];
@@ -354,8 +349,8 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     const u32 none = 0xFFFFFFFFu;
     next_keys[2 * (size_t)sj] = none;                          // this lane's two edge slots (lane sj of the edge arrays): unused until msm_flush says otherwise
     next_keys[2 * (size_t)sj + 1] = none;
-    const u32 first_pos = range_base + (range_lo ? *range_lo : 0u);
-    const u32 end_pos = range_end ? range_base + *range_end : len;
+    const u32 first_pos = range_lo ? *range_lo : 0u;
+    const u32 end_pos = range_end ? *range_end : len;
     const u64 lo64 = (u64)first_pos + (u64)j * T;
     if (lo64 >= end_pos) return;
     const u32 lo = (u32)lo64;
@@ -363,8 +358,7 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     const uint2 cur = pairs[lo];
     u32 cur_key = cur.x;
     if (cur_key >= nbuckets) return;                           // zero digits sort behind every bucket: nothing to add
-    // neighbours outside the launch's own part of the list belong to another window (another key) -- or, when every group
-    // of windows is sorted on its own, to a part that is not sorted yet
+    // neighbours outside the launch's own part of the list belong to another window (another key)
     const u32 prev_key = lo > first_pos ? pairs[lo - 1].x : none;
     const u32 next_key = hi < end_pos ? pairs[hi].x : none;
     auto fetch = [&](u32 v) {
@@ -410,17 +404,17 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
 }
 extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 range_base, u32 nlanes, u32 slot0, u32 rec_words)
+                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0, u32 rec_words)
 {
     const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
-    if (j < nlanes) msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, range_base, j, slot0 + j, rec_words);
+    if (j < nlanes) msm_runs_body<false>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j, rec_words);
 }
 extern "C" __global__ __launch_bounds__(ZC_MSM_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(ZC_MSM_WAVES)))
 void k_msm_runs_affine(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 range_base, u32 nlanes, u32 slot0, u32 rec_words)
+                       u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 nlanes, u32 slot0, u32 rec_words)
 {
     const u32 j = blockIdx.x * MSM_RUN_BLOCK + threadIdx.x;
-    if (j < nlanes) msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, range_base, j, slot0 + j, rec_words);
+    if (j < nlanes) msm_runs_body<true>(pairs, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs, range_lo, range_end, j, slot0 + j, rec_words);
 }
 
 // Levels >= 1: the edge list of the level above (raw 144-byte records in list order, sentinel keys in

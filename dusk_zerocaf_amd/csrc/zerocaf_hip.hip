@@ -74,6 +74,7 @@ struct Tuning {
     int msm_fork = -1;               // ZC_MSM_FORK=0/1
     int msm_affine_chunk = 0;        // ZC_MSM_AFFINE_CHUNK=c (1..64)
     int msm_seg = 0;                 // ZC_MSM_SEG=s (power of two, 2..256)
+    long test_stream_min = 0;        // ZC_TEST_STREAM_MIN_BYTES=b: the 40-byte element ops take their LDS-staged kernels from b bytes per call on
     bool test_ring_poison = false;   // ZC_TEST_RING_POISON: pretend a wave of every windowed-core launch gave up
     unsigned test_ring_spins = 0;    // ZC_TEST_RING_SPINS=b: waves give up after 2^b polls (default 22, about 4 s)
 };
@@ -118,6 +119,7 @@ Tuning tuning_from_env()
         const long f = env_long("ZC_MSM_SEG", 2, 256, 0);
         if (f && (f & (f - 1)) == 0) t.msm_seg = (int)f;
     }
+    t.test_stream_min = env_long("ZC_TEST_STREAM_MIN_BYTES", 1, 1l << 40, 0);
     t.test_ring_poison = getenv("ZC_TEST_RING_POISON") != nullptr;
     t.test_ring_spins = (unsigned)env_long("ZC_TEST_RING_SPINS", 1, 30, 0);
 #endif
@@ -159,7 +161,7 @@ struct DevState {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t grp = nullptr;          // MSM window groups: the chains of the groups above the lowest one, one after the other (highest priority)
     hipEvent_t ev_grp_go[3] = {}, ev_grp_done[3] = {};   // group g's bucket sums are enqueued / its chain is through
-    hipEvent_t ev_digits = nullptr, ev_sorted[4] = {};   // the digit words are written / group g's keys are sorted (groups sorted on their own)
+    unsigned long long staged_launches = 0;   // element-wise / point launches that took the LDS-staged kernel (read by the test build's zc_test_staged_launches)
     hipStream_t s() const { return use_borrowed ? borrowed : stream; }
 };
 
@@ -407,14 +409,24 @@ constexpr size_t STREAM_BYTES = (size_t)256 << 20;
 
 // `stream_min`: the call's bytes from which the staged kernel wins (STREAM_BYTES for the 40-byte element ops; the point ops
 // -- 160-byte records, far beyond what a lane reads well on its own -- from the first full launch on).
+// The test build can lower the 40-byte ops' threshold (ZC_TEST_STREAM_MIN_BYTES) so that small batches reach the staged kernels.
+inline size_t staged_min(const DevState& D, size_t elt, size_t stream_min)
+{
+#ifdef ZC_TEST_HOOKS
+    if (elt == 40 && D.tune.test_stream_min > 0) return (size_t)D.tune.test_stream_min;
+#endif
+    (void)D; (void)elt;
+    return stream_min;
+}
 int binop(zc_ctx* ctx, kbin_t k, kbin_t k_stream, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t elt, size_t stream_min = STREAM_BYTES)
 {
     REQUIRE(a); REQUIRE(b); REQUIRE(out);
     // elt == 0: (point, scalar) -> point
     Arg args[3] = {in_arg(a, elt ? elt : 160), in_arg(b, elt ? elt : 40), out_arg(out, elt ? elt : 160)};
     return run_batched(ctx, args, 3, n, [&](void** d, size_t cnt, DevState& D) {
-        const bool stream = k_stream && cnt * elt * 3 > stream_min && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
+        const bool stream = k_stream && cnt * elt * 3 > staged_min(D, elt, stream_min) && aligned16(d[0]) && aligned16(d[1]) && aligned16(d[2]);
         const unsigned blk = stream && elt == 160 ? (unsigned)zc::ED_STAGED_BLOCK : (unsigned)zc::ZC_BLOCK;     // the staged point kernels have their own workgroup size
+        D.staged_launches += stream ? 1 : 0;
         hipLaunchKernelGGL(stream ? k_stream : k, dim3((unsigned)((cnt + blk - 1) / blk)), dim3(blk), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], cnt);
     }, elt == 0);
 }
@@ -423,8 +435,9 @@ int unop(zc_ctx* ctx, kun_t k, const uint64_t* a, uint64_t* out, size_t n, size_
     REQUIRE(a); REQUIRE(out);
     Arg args[2] = {in_arg(a, elt), out_arg(out, elt)};
     return run_batched(ctx, args, 2, n, [&](void** d, size_t cnt, DevState& D) {
-        const bool stream = k_stream && cnt * elt * 2 > stream_min && aligned16(d[0]) && aligned16(d[1]);
+        const bool stream = k_stream && cnt * elt * 2 > staged_min(D, elt, stream_min) && aligned16(d[0]) && aligned16(d[1]);
         const unsigned blk = stream && elt == 160 ? (unsigned)zc::ED_STAGED_BLOCK : (unsigned)zc::ZC_BLOCK;
+        D.staged_launches += stream ? 1 : 0;
         hipLaunchKernelGGL(stream ? k_stream : k, dim3((unsigned)((cnt + blk - 1) / blk)), dim3(blk), 0, D.s(), (const u64*)d[0], (u64*)d[1], cnt);
     });
 }
@@ -858,17 +871,10 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         zc::u32* digits = cv.take<zc::u32>(m);
         uint2* pairs_a = cv.take<uint2>(m);
         void* pairs_b = plan.passes == 1 ? nullptr : plan.packed ? (void*)cv.take<zc::u32>(m) : (void*)cv.take<uint2>(m);
-        // one sort for all windows, or -- window groups -- one per group (its own tables: the bucket sums read a group's last scan table)
-        const bool sort_per_group = G > 1 && ZC_MSM_SORT_PER_GROUP != 0;
-        zc::u32* sort_table[4] = {};
-        zc::u32* sort_sums[4] = {};
-        size_t sort_table_words[4] = {};
-        for (int g = 0; g < (sort_per_group ? G : 1); g++) {
-            const size_t nw = sort_per_group ? (size_t)grp[g].nw : (size_t)W;
-            for (int i = 0; i < plan.passes; i++) sort_table_words[g] = std::max(sort_table_words[g], msm_sort_table_words(plan.pass[i], nw));
-            sort_table[g] = cv.take<zc::u32>(2 * sort_table_words[g]);
-            sort_sums[g] = cv.take<zc::u32>(sort_table_words[g] / zc::SCAN_BLOCK_ELEMS + 1);
-        }
+        // one sort for all windows (a sort per window group under the bucket sums of the group above was built and measured in
+        // round 5 -- not taken; the patch: tools/debug/probes/msm_sort_per_group.patch)
+        zc::u32* sort_table = cv.take<zc::u32>(2 * plan.table_words);
+        zc::u32* sort_sums = cv.take<zc::u32>(plan.table_words / zc::SCAN_BLOCK_ELEMS + 1);
         zc::u32* cached = cv.take<zc::u32>(cnt * 32);
         zc::u32* buckets = cv.take<zc::u32>(nb * zc::MSM_RAW_WORDS);
         uint8_t* present = cv.take<uint8_t>(nb);
@@ -907,42 +913,26 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         if (ps != D.s()) HIP_TRY(hipEventRecord(D.ev_join, ps));
         hipLaunchKernelGGL(zc::k_msm_digits, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), dK, digits, cnt, c, W);
         const uint2* sorted = pairs_a;
-        // The key sort.  With window groups every group is sorted on its own, top group first: its bucket sums start as soon as
-        // ITS keys are in order (and the points are normalised), and the sorts of the groups below -- memory- and LDS-bound --
-        // run under those bucket sums -- multiplier-bound -- on the side stream the normalisation has just left.
+        // The key sort
         HIP_TRY(hipMemsetAsync(present, 0, nb, D.s()));       // one flag per bucket: record written (else: empty = identity)
-        hipStream_t side = ps != D.s() ? ps : D.s();            // behind the normalisation (the low-priority stream), or in line
-        if (sort_per_group) {
-            if (side != D.s()) {
-                HIP_TRY(hipEventRecord(D.ev_digits, D.s()));
-                HIP_TRY(hipStreamWaitEvent(side, D.ev_digits, 0));
-            }
-            // the top group's keys now; the others are enqueued behind the top group's bucket-sum launch (below): the host
-            // enqueues a hundred small launches per call, and what the chip needs first has to be enqueued first
-            if (int rc = msm_sort(D, D.s(), plan, grp[0].w0, grp[0].nw, digits, pairs_a, pairs_b, sort_table[0], sort_table_words[0], sort_sums[0])) return rc;
-        } else {
-            if (int rc = msm_sort(D, D.s(), plan, 0, W, digits, pairs_a, pairs_b, sort_table[0], sort_table_words[0], sort_sums[0])) return rc;
-        }
+        if (int rc = msm_sort(D, D.s(), plan, 0, W, digits, pairs_a, pairs_b, sort_table, plan.table_words, sort_sums)) return rc;
         if (ps != D.s()) HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_join, 0));
         // where window w's part of the sorted list starts: the last pass's scanned table at (window w, bin 0, column 0); the row
-        // behind the last window is the zero digits' = the end of the buckets (zc_sort.hip.h: msm_sort_slot).  A group sorted on
-        // its own counts from the start of its own part of the list.
+        // behind the last window is the zero digits' = the end of the buckets (zc_sort.hip.h: msm_sort_slot).
         const zc::msm_sort_pass& lastp = plan.pass[plan.passes - 1];
-        auto window_start = [&](int g, int w) {
-            const int ti = sort_per_group ? g : 0;
-            const zc::u32* last_table = sort_table[ti] + (size_t)((plan.passes - 1) & 1) * sort_table_words[ti];
-            return last_table + ((size_t)(sort_per_group ? w - grp[g].w0 : w) << lastp.bits) * lastp.ncols;
+        auto window_start = [&](int w) {
+            const zc::u32* last_table = sort_table + (size_t)((plan.passes - 1) & 1) * plan.table_words;
+            return last_table + ((size_t)w << lastp.bits) * lastp.ncols;
         };
         for (int g = 0; g < G; g++) {
             Group& gr = grp[g];
-            if (sort_per_group && g > 0 && ps != D.s()) HIP_TRY(hipStreamWaitEvent(D.s(), D.ev_sorted[g], 0));
             const size_t b0 = (size_t)gr.w0 << (c - 1);                  // the group's first bucket
             const size_t nsegg = (size_t)gr.nw * spw;
             // A launch that runs beside the chain of the group above it leaves that chain room: its workgroups are padded with
             // dynamic LDS so that only `wgs` of them fit a CU (three: one wave slot per SIMD, 200 VGPRs and 39 KB of LDS stay free;
             // a chain kernel that finds every slot taken waits for a bucket-sum workgroup to retire).
             size_t pad = 0;
-            if (g > 0 || sort_per_group) {                       // (the top group's launch runs beside the sorts of the groups below it)
+            if (g > 0) {
                 const long wgs = ZC_MSM_GROUP_WGS;
                 const size_t own = (affine ? 6 : 8) * 16 * (size_t)zc::MSM_RUN_BLOCK;       // the kernel's static staging area
                 if (wgs > 0 && (size_t)(wgs + 1) * own <= 163840) {
@@ -952,14 +942,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             }
             hipLaunchKernelGGL(affine ? zc::k_msm_runs_affine : zc::k_msm_runs, dim3((unsigned)((gr.nl0 + zc::MSM_RUN_BLOCK - 1) / zc::MSM_RUN_BLOCK)), dim3(zc::MSM_RUN_BLOCK), pad,
                                D.s(), sorted, (const zc::u32*)cached, (zc::u32)m, (zc::u32)gr.T, (zc::u32)nb, buckets, present, ekeys[0], erecs[0],
-                               G == 1 ? (const zc::u32*)nullptr : window_start(g, gr.w0), G == 1 ? (const zc::u32*)nullptr : window_start(g, gr.w0 + gr.nw),
-                               sort_per_group ? (zc::u32)((size_t)gr.w0 * cnt) : 0u, (zc::u32)gr.nl0, (zc::u32)gr.slot0, rec_words);
-            if (sort_per_group && g == 0) {
-                for (int h = 1; h < G; h++) {
-                    if (int rc = msm_sort(D, side, plan, grp[h].w0, grp[h].nw, digits, pairs_a, pairs_b, sort_table[h], sort_table_words[h], sort_sums[h])) return rc;
-                    if (side != D.s()) HIP_TRY(hipEventRecord(D.ev_sorted[h], side));
-                }
-            }
+                               G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0), G == 1 ? (const zc::u32*)nullptr : window_start(gr.w0 + gr.nw),
+                               (zc::u32)gr.nl0, (zc::u32)gr.slot0, rec_words);
             hipStream_t st = ZC_MSM_TAIL_SIDE ? gr.st : D.s();
             if (st != D.s()) {
                 HIP_TRY(hipEventRecord(D.ev_grp_go[g], D.s()));
@@ -1105,7 +1089,7 @@ extern "C" {
 #ifndef ZC_SRC_HASH
 #define ZC_SRC_HASH "unknown"
 #endif
-const char* zc_version(void) { return "zerocaf_hip 0.4 (gfx950, radix-2^29 Montgomery R=2^261) src:" ZC_SRC_HASH; }
+const char* zc_version(void) { return "zerocaf_hip 0.5 (gfx950, radix-2^29 Montgomery R=2^261) src:" ZC_SRC_HASH; }
 const char* zc_last_error(void) { return g_last_error.c_str(); }
 
 int zc_device_count(void)
@@ -1159,8 +1143,6 @@ int zc_ctx_create(const int* devices, int ndev, zc_ctx** out)
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
             e = hipStreamCreateWithPriority(&ds.grp, hipStreamNonBlocking, ZC_MSM_TAIL_PRIO ? hi_p : 0);
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_digits, hipEventDisableTiming);
-        for (int g = 0; g < 4 && e == hipSuccess; g++) e = hipEventCreateWithFlags(&ds.ev_sorted[g], hipEventDisableTiming);
         for (int g = 0; g < 3 && e == hipSuccess; g++) {
             e = hipEventCreateWithFlags(&ds.ev_grp_go[g], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ds.ev_grp_done[g], hipEventDisableTiming);
@@ -1196,9 +1178,6 @@ int zc_ctx_destroy(zc_ctx* ctx)
         if (ds.ev_join) (void)hipEventDestroy(ds.ev_join);
         if (ds.aux) (void)hipStreamDestroy(ds.aux);
         if (ds.grp) (void)hipStreamSynchronize(ds.grp), (void)hipStreamDestroy(ds.grp);
-        if (ds.ev_digits) (void)hipEventDestroy(ds.ev_digits);
-        for (int g = 0; g < 4; g++)
-            if (ds.ev_sorted[g]) (void)hipEventDestroy(ds.ev_sorted[g]);
         for (int g = 0; g < 3; g++) {
             if (ds.ev_grp_go[g]) (void)hipEventDestroy(ds.ev_grp_go[g]);
             if (ds.ev_grp_done[g]) (void)hipEventDestroy(ds.ev_grp_done[g]);
@@ -1282,8 +1261,13 @@ int zc_fe_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size
 #ifndef ZC_MULSQ_STAGED_MIN_BYTES
 #define ZC_MULSQ_STAGED_MIN_BYTES STREAM_BYTES
 #endif
+// Neg: one input array, no arithmetic to speak of.  Round 6 A/B at 2^24 / 2^26 decides whether the staged form ships
+// (profiles/r06_experiments/neg_staged_ab.md); a kernel without a launch site is not kept.
+#ifndef ZC_NEG_STAGED
+#define ZC_NEG_STAGED 1
+#endif
 int zc_fe_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_fe_mul, ZC_MULSQ_STAGED ? zc::k_fe_mul_stream : nullptr, a, b, o, n, 40, ZC_MULSQ_STAGED_MIN_BYTES); }
-int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40); }
+int zc_fe_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_neg, a, o, n, 40, ZC_NEG_STAGED ? zc::k_fe_neg_stream : nullptr); }
 int zc_fe_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_fe_square, a, o, n, 40, ZC_MULSQ_STAGED ? zc::k_fe_square_stream : nullptr, ZC_MULSQ_STAGED_MIN_BYTES); }
 
 // Montgomery's trick shares one inversion among the c consecutive elements of a lane (3 multiplications per
@@ -1390,7 +1374,7 @@ int zc_fe_inv_sqrt(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* was_s
 int zc_sc_add(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_add, zc::k_sc_add_stream, a, b, o, n, 40); }
 int zc_sc_sub(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_sub, zc::k_sc_sub_stream, a, b, o, n, 40); }
 int zc_sc_mul(zc_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return binop(c, zc::k_sc_mul, ZC_MULSQ_STAGED ? zc::k_sc_mul_stream : nullptr, a, b, o, n, 40, ZC_MULSQ_STAGED_MIN_BYTES); }
-int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40); }
+int zc_sc_neg(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_neg, a, o, n, 40, ZC_NEG_STAGED ? zc::k_sc_neg_stream : nullptr); }
 int zc_sc_square(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_square, a, o, n, 40, ZC_MULSQ_STAGED ? zc::k_sc_square_stream : nullptr, ZC_MULSQ_STAGED_MIN_BYTES); }
 // S-x rows: the Scalar operations beside the default scalar-mul path
 int zc_sc_half(zc_ctx* c, const uint64_t* a, uint64_t* o, size_t n) { return unop(c, zc::k_sc_half, a, o, n, 40); }
@@ -1433,11 +1417,12 @@ int zc_sc_to_bytes(zc_ctx* ctx, const uint64_t* in, uint8_t* out32, size_t n) { 
 
 // ---- EdwardsPoint
 // staged records from 2^12 points on (below, a launch is a handful of workgroups and the barriers only cost)
-constexpr size_t ED_STAGED_MIN_BYTES = (size_t)160 * 3 << 12;
+constexpr size_t ED_STAGED_MIN_BYTES = (size_t)160 * 3 << 12;     // binop compares cnt * 160 * 3 against it: above 2^12 points
+constexpr size_t ED_STAGED_MIN_BYTES_1 = (size_t)160 * 2 << 12;   // unop compares cnt * 160 * 2: the same 2^12 points for double / neg
 int zc_ed_add(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_add, zc::k_ed_add_staged, p, q, o, n, 160, ED_STAGED_MIN_BYTES); }
 int zc_ed_sub(zc_ctx* c, const uint64_t* p, const uint64_t* q, uint64_t* o, size_t n) { return binop(c, zc::k_ed_sub, zc::k_ed_sub_staged, p, q, o, n, 160, ED_STAGED_MIN_BYTES); }
-int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160, zc::k_ed_double_staged, ED_STAGED_MIN_BYTES); }
-int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160, zc::k_ed_neg_staged, ED_STAGED_MIN_BYTES); }
+int zc_ed_double(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_double, p, o, n, 160, zc::k_ed_double_staged, ED_STAGED_MIN_BYTES_1); }
+int zc_ed_neg(zc_ctx* c, const uint64_t* p, uint64_t* o, size_t n) { return unop(c, zc::k_ed_neg, p, o, n, 160, zc::k_ed_neg_staged, ED_STAGED_MIN_BYTES_1); }
 
 int zc_ed_scalar_mul(zc_ctx* ctx, const uint64_t* p, const uint64_t* k, uint64_t* out, size_t n, unsigned flags)
 {
@@ -1856,6 +1841,16 @@ int zc_test_odd_table(zc_ctx* ctx, uint64_t* out_dev_points)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(D.s()));
     return ZC_OK;
+}
+// Test hook: how many element-wise / point launches of this context took their LDS-staged kernel so far (all device slots).
+// Lets a parity test assert that the staged kernel -- not the per-lane one -- produced the output it compared.
+long long zc_test_staged_launches(zc_ctx* ctx)
+{
+    if (!ctx) return -1;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    unsigned long long t = 0;
+    for (auto& d : ctx->devs) t += d.staged_launches;
+    return (long long)t;
 }
 #endif  // ZC_TEST_HOOKS
 

@@ -46,7 +46,10 @@ class Engine:
         # slot i of the context = HIP device _devices[i], as the context itself reports it: always known, so the
         # ownership check of _follow_torch_stream always runs
         self._devices = [self.lib.zc_ctx_device(self.ctx, i) for i in range(self.lib.zc_ctx_device_count(self.ctx))]
-        assert not devices or self._devices == list(devices), (self._devices, devices)
+        if any(d < 0 for d in self._devices) or (devices and self._devices != list(devices)):
+            got = self._devices
+            self.close()
+            raise _lib.ZerocafHipError("zc_ctx_create: the context reports devices %s, asked for %s" % (got, list(devices)))
 
     def close(self):
         if self.ctx:

@@ -68,8 +68,8 @@ def test_release_library_carries_no_test_hooks_and_reads_its_knobs_once(lib):
     assert "zc_test_" not in rel
     assert b"ZC_TEST_" not in open(z.LIB_PATH, "rb").read()
     tst = subprocess.check_output(["nm", "-D", "--defined-only", _lib.TEST_LIB_PATH], text=True)
-    assert {"zc_test_msm_sort", "zc_test_odd_table"} <= set(re.findall(r"\bT (zc_[a-z0-9_]+)", tst))
-    assert set(re.findall(r"\bT (zc_[a-z0-9_]+)", rel)) == set(re.findall(r"\bT (zc_[a-z0-9_]+)", tst)) - {"zc_test_msm_sort", "zc_test_odd_table"}
+    assert {"zc_test_msm_sort", "zc_test_odd_table", "zc_test_staged_launches"} <= set(re.findall(r"\bT (zc_[a-z0-9_]+)", tst))
+    assert set(re.findall(r"\bT (zc_[a-z0-9_]+)", rel)) == set(re.findall(r"\bT (zc_[a-z0-9_]+)", tst)) - {"zc_test_msm_sort", "zc_test_odd_table", "zc_test_staged_launches"}
     src = ""
     for f in os.listdir(os.path.join(ROOT, "dusk_zerocaf_amd", "csrc")):
         if f.endswith((".hip", ".h")):
@@ -87,7 +87,7 @@ def test_release_library_carries_no_test_hooks_and_reads_its_knobs_once(lib):
                        "ZC_RING_SLOTS", "ZC_RISTRETTO_STRICT", "ZC_SCHED"], product
     hooks_only = sorted(x.decode() for x in strings(_lib.TEST_LIB_PATH) - strings(z.LIB_PATH))
     assert hooks_only == ["ZC_MSM_AFFINE_CHUNK", "ZC_MSM_FORK", "ZC_MSM_RUN", "ZC_MSM_RUN_EDGES", "ZC_MSM_SEG", "ZC_MSM_SORT_BIG", "ZC_MSM_SORT_G",
-                          "ZC_MSM_SORT_PACKED", "ZC_TEST_RING_POISON", "ZC_TEST_RING_SPINS"], hooks_only
+                          "ZC_MSM_SORT_PACKED", "ZC_TEST_RING_POISON", "ZC_TEST_RING_SPINS", "ZC_TEST_STREAM_MIN_BYTES"], hooks_only
     assert "PROBE" not in src                                # timing probes live in tools/debug/probes/*.patch
     assert "env_long(" in body and outside.count("env_long(") == 1                      # its definition only
 

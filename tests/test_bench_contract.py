@@ -30,6 +30,33 @@ def _one_json_line(out):
     return d
 
 
+def test_spot_check_sample_covers_head_tail_and_a_stride_through_the_middle():
+    """bench.py's oracle spot check (and CPU baseline sample) is spread over the whole batch: the first quarter of the
+    sample from the head, the last quarter from the tail -- the ragged last workgroup, the end of a persistent kernel's
+    schedule -- and a seeded jittered stride through everything between them.  Deterministic, sorted, no duplicates, the
+    unit count asked for; the middle visits every residue modulo the wave / workgroup / tile sizes."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    for n, m in ((1 << 20, 1 << 17), (1 << 24, 1 << 18), (1 << 22, 2048), ((1 << 21), 4096), (300000, 4096), (1000, 64), (7, 3)):
+        idx = bench.spread_sample(n, m)
+        assert len(idx) == m and idx.dtype == np.int64 and np.array_equal(idx, bench.spread_sample(n, m))
+        assert np.all(np.diff(idx) > 0) and 0 <= idx[0] and idx[-1] < n and (m < 4 or (idx[0] == 0 and idx[-1] == n - 1))
+        h = m // 4
+        assert np.array_equal(idx[:h], np.arange(h)) and np.array_equal(idx[m - h:], np.arange(n - h, n))
+        mid = idx[h:m - h]
+        step = (n - 2 * h) // len(mid)
+        assert np.all(mid >= h) and np.all(mid < n - h)
+        assert np.array_equal((mid - h) // step, np.arange(len(mid)))         # one unit out of every `step` consecutive ones
+        if len(mid) >= 4096 and step > 1:
+            for mod in (64, 256, 4096):
+                assert len(np.unique(mid % mod)) == mod, (n, m, mod)   # every residue occurs
+        # the eighths of the batch are all visited
+        if m >= 64:
+            assert len(np.unique(idx * 8 // n)) == 8
+    assert np.array_equal(bench.spread_sample(100, 100), np.arange(100)) and np.array_equal(bench.spread_sample(100, 1000), np.arange(100))
+
+
 @pytest.mark.gpu
 def test_single_rank_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "4096"],
@@ -43,6 +70,7 @@ def test_single_rank_line():
     assert r["measured_rate"]["v_mad_u64_u32_T_lane_ops_per_s"] > 10 and 0 < r["measured_rate"]["frac"] < 1.05
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_single_core"] > 0
+    assert "spread over the whole batch" in c["sample"] and "head" in c["sample"] and "tail" in c["sample"] and "stride" in c["sample"]
     assert d["distinct_devices"] == 1 and len(d["devices"]) == 1 and d["devices"][0]["pci"]
     assert d["config"]["units_per_gpu_per_step"] == 1 << 20 and abs(d["value"] - (1 << 20) / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
     assert d["config"]["workload"].startswith("2^20 ") and r["schema"] == "useful-work/2" and "-march=" in c["sample"]

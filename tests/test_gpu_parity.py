@@ -219,6 +219,92 @@ def test_streaming_add_sub_2_22(eng, oracle):
         assert eq(add(a, b), oadd(a, b)) and eq(sub(a, b), osub(a, b))
 
 
+def _staged_inputs(n, seed, mod, edge, topbit, raw_every):
+    """Canonical operands with the edge set at the head, across a workgroup boundary in the middle and in the ragged last
+    workgroup; with `raw_every`, every raw_every-th element of `a` (and a sparser set of `b`) is a raw 5 x 52-bit
+    pattern at or above 2^topbit, so that both product forms occur inside one staged block."""
+    a, b = V.rand_fe_np(n, seed, mod), V.rand_fe_np(n, seed + 1, mod)
+    E = V.limbs_array(edge)
+    k = min(len(edge), n)
+    for off in sorted({0, max(0, min(n - k, 256 * 1000 - k // 2)), n - k}):
+        a[off:off + k] = E[:k]
+        b[off:off + k] = E[::-1][:k]
+    if raw_every:
+        rng = np.random.default_rng(seed + 2)
+        for arr, first, step in ((a, 3, raw_every), (b, 5, 3 * raw_every)):
+            idx = np.arange(first, n, step)
+            raw = rng.integers(0, 1 << 52, size=(len(idx), 5), dtype=np.uint64)
+            raw[:, 4] |= np.uint64(1 << (topbit - 208))                 # at or above 2^topbit whatever the other bits
+            arr[idx] = raw
+    return a, b
+
+
+@pytest.mark.parametrize("raw_every", [0, 8])
+def test_staged_mul_square_neg_kernels_every_output(eng, oracle, raw_every):
+    """Beyond 256 MB per call Mul / Square / Neg move their 40-byte records through LDS (k_fe_mul_stream, k_fe_square_stream,
+    k_fe_neg_stream and the scalar forms; zerocaf_hip.hip: binop / unop).  EVERY output of device-resident batches of
+    2^22 + 3 (mul) and 2^23 - 5 (square, neg) elements -- ragged last workgroups -- against the oracle's Mul / Square / Neg
+    (field.rs:250-262, :302-315, :217-240; scalar.rs:247-283): canonical operands with the edge set, then with every
+    8th element a raw pattern at or above 2^T, which makes the wave take the two-pass product inside a staged block.
+    The test build's launch counter proves that the staged kernel produced what was compared; an array 8 bytes off a
+    16-byte boundary must fall back to the per-lane kernel and agree; the product library on the same arrays agrees."""
+    import torch
+    n_mul, n_sq = (1 << 22) + 3, (1 << 23) - 5
+    dev = lambda x: torch.from_numpy(x.view(np.int64)).cuda()
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+
+    def off8(t):                                                       # the same rows, 8 bytes off a 16-byte boundary
+        flat = torch.empty(t.numel() + 1, dtype=torch.int64, device="cuda")
+        v = flat[1:].view(t.shape)
+        assert v.data_ptr() % 16 == 8
+        v.copy_(t)
+        return v
+
+    with V.tuned(hooks=True) as te:
+        count = lambda: te.lib.zc_test_staged_launches(te.ctx)
+        for pre, mod, edge, topbit in (("fe", pm.P, V.FE_EDGE, 252), ("sc", pm.L, V.SC_EDGE, 249)):
+            a, b = _staged_inputs(n_sq, V.SEED + 900 + raw_every + topbit, mod, edge, topbit, raw_every)
+            am, bm = np.ascontiguousarray(a[:n_mul]), np.ascontiguousarray(b[:n_mul])
+            want_mul = oracle.mt(getattr(oracle, pre + "_mul"), am, bm)
+            want_sq = oracle.mt(getattr(oracle, pre + "_square"), a)
+            want_neg = oracle.mt(getattr(oracle, pre + "_neg"), a)
+            dA, dB, dAm, dBm = dev(a), dev(b), dev(am), dev(bm)
+            for name, args, want in ((pre + "_mul", (dAm, dBm), want_mul), (pre + "_square", (dA,), want_sq), (pre + "_neg", (dA,), want_neg)):
+                c0 = count()
+                got = getattr(te, name)(*args)
+                torch.cuda.synchronize()
+                assert count() == c0 + 1, name + ": the staged kernel did not run"
+                assert eq(host(got), want), name
+                got = getattr(eng, name)(*args)                        # the product library, same arrays
+                torch.cuda.synchronize()
+                assert eq(host(got), want), name + " (product build)"
+                c0 = count()
+                got = getattr(te, name)(off8(args[0]), *args[1:])      # misaligned first operand: per-lane kernel
+                torch.cuda.synchronize()
+                assert count() == c0 and eq(host(got), want), name + " (misaligned)"
+            del dA, dB, dAm, dBm
+            if pre == "fe" and not raw_every:                          # host pointers: the library's own (aligned) staging buffers
+                c0 = count()
+                assert eq(te.fe_mul(am, bm), want_mul) and count() == c0 + 1
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [1, 255, 257, (1 << 16) + 3])
+def test_staged_elementwise_kernels_at_small_sizes(oracle, n):
+    """ZC_TEST_STREAM_MIN_BYTES (test build) lowers the 256 MB threshold, so that every LDS-staged 40-byte kernel -- add, sub,
+    neg, mul, square, field and scalar -- also runs at sizes with one ragged workgroup, one lane, one lane more than a
+    workgroup (tools/soak.py reaches them the same way): all outputs against the oracle, raw patterns every 5th element."""
+    with V.tuned(hooks=True, ZC_TEST_STREAM_MIN_BYTES=1) as te:
+        for pre, mod, edge, topbit in (("fe", pm.P, V.FE_EDGE, 252), ("sc", pm.L, V.SC_EDGE, 249)):
+            a, b = _staged_inputs(n, V.SEED + 950 + n + topbit, mod, edge, topbit, 5)
+            c0 = te.lib.zc_test_staged_launches(te.ctx)
+            for name in ("add", "sub", "mul"):
+                assert eq(getattr(te, pre + "_" + name)(a, b), getattr(oracle, pre + "_" + name)(a, b)), (pre, name)
+            for name in ("neg", "square"):
+                assert eq(getattr(te, pre + "_" + name)(a), getattr(oracle, pre + "_" + name)(a)), (pre, name)
+            assert te.lib.zc_test_staged_launches(te.ctx) == c0 + 5
+
+
 def test_fe_invert_bulk(eng, oracle):
     n = (1 << 14) + 3
     a = V.rand_fe_np(n, V.SEED + 22)

@@ -40,11 +40,13 @@ def main():
                 enc = eng.ris_compress(pts)
                 edc, _ = eng.ed_compress(pts)
             bytes_per = {"fe_add": 120, "fe_sub": 120, "fe_mul": 120, "fe_square": 80, "fe_neg": 80, "fe_invert": 80, "fe_div": 120,
-                         "sc_mul": 120, "ed_add": 480, "ed_double": 320, "ed_compress": 192, "ed_decompress": 192,
+                         "sc_mul": 120, "sc_mul_raw": 120, "sc_square": 80, "sc_square_raw": 80, "sc_neg": 80, "ed_add": 480, "ed_double": 320, "ed_compress": 192, "ed_decompress": 192,
                          "ris_compress": 192, "ris_decompress": 192, "ed_to_affine": 240, "fe_sqrt_ratio_i": 120, "fe_legendre": 41, "ed_neg": 320, "ed_eq": 321, "ris_eq": 321, "ed_is_valid": 161, "ed_mul_base": 200, "ris_mul_base_compress": 72, "ed_mul_base_wnaf5": 200}[op]
             fn = {"fe_add": lambda: eng.fe_add(a, b), "fe_sub": lambda: eng.fe_sub(a, b), "fe_mul": lambda: eng.fe_mul(a, b),
                   "fe_square": lambda: eng.fe_square(a), "fe_neg": lambda: eng.fe_neg(a), "fe_invert": lambda: eng.fe_invert(a), "fe_div": lambda: eng.fe_div(a, b),
-                  "sc_mul": lambda: eng.sc_mul(sa, sb), "fe_sqrt_ratio_i": lambda: eng.fe_sqrt_ratio_i(a, b), "fe_legendre": lambda: eng.fe_legendre_symbol(a),
+                  "sc_mul": lambda: eng.sc_mul(sa, sb), "sc_square": lambda: eng.sc_square(sa), "sc_neg": lambda: eng.sc_neg(sa),
+                  # raw 252-bit patterns as scalars: 7 of 8 at or above 2^249, the two-pass product
+                  "sc_mul_raw": lambda: eng.sc_mul(a, b), "sc_square_raw": lambda: eng.sc_square(a), "fe_sqrt_ratio_i": lambda: eng.fe_sqrt_ratio_i(a, b), "fe_legendre": lambda: eng.fe_legendre_symbol(a),
                   "ed_add": lambda: eng.ed_add(pts, pts2), "ed_double": lambda: eng.ed_double(pts),
                   "ed_compress": lambda: eng.ed_compress(pts), "ed_decompress": lambda: eng.ed_decompress(edc),
                   "ris_compress": lambda: eng.ris_compress(pts), "ris_decompress": lambda: eng.ris_decompress(enc),

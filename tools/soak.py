@@ -115,4 +115,19 @@ Km[rng.choice(nm, size=nm // 100 + 1, replace=False)] = rng.integers(0, 1 << 52,
 Pm = np.tile(P, (nm // n + 1, 1))[:nm].copy()
 got, want = eng.msm(Pm, Km), zc_ref.msm_naive_mt(Pm, Km)
 assert zc_ref.ed_eq(got, want)[0] == 1 and np.array_equal(zc_ref.ed_compress(got)[0], zc_ref.ed_compress(want)[0]), "msm n=%d bits=%d" % (nm, bits)
-print("soak seed %d ok in %.1f s (persistent-wave n=%d, msm n=%d bits=%d)" % (seed, time.time() - t0, nb, nm, bits))
+# the LDS-staged 40-byte kernels (product: beyond 256 MB per call) at a random ragged size through the test build's threshold
+# override: canonical operands with raw patterns (>= 2^T: the two-pass product inside a staged block) mixed in
+ne = int(rng.integers(1, 1 << 17))
+with V.tuned(hooks=True, ZC_TEST_STREAM_MIN_BYTES=1) as te:
+    for pre, mod, top in (("fe", pm.P, 252), ("sc", pm.L, 249)):
+        xa, xb = V.rand_fe_np(ne, seed * 100 + 50 + top, mod), V.rand_fe_np(ne, seed * 100 + 51 + top, mod)
+        wild = rng.choice(ne, size=ne // int(rng.integers(2, 40)) + 1, replace=False)
+        xa[wild] = rng.integers(0, 1 << 52, size=(len(wild), 5), dtype=np.uint64)
+        xb[wild[::3]] = rng.integers(0, 1 << 52, size=(len(wild[::3]), 5), dtype=np.uint64)
+        c0 = te.lib.zc_test_staged_launches(te.ctx)
+        for op in ("add", "sub", "mul"):
+            assert np.array_equal(getattr(te, pre + "_" + op)(xa, xb), par(getattr(zc_ref, pre + "_" + op), ne, xa, xb)), "staged %s_%s n=%d" % (pre, op, ne)
+        for op in ("neg", "square"):
+            assert np.array_equal(getattr(te, pre + "_" + op)(xa), par(getattr(zc_ref, pre + "_" + op), ne, xa)), "staged %s_%s n=%d" % (pre, op, ne)
+        assert te.lib.zc_test_staged_launches(te.ctx) == c0 + 5
+print("soak seed %d ok in %.1f s (persistent-wave n=%d, msm n=%d bits=%d, staged element ops n=%d)" % (seed, time.time() - t0, nb, nm, bits, ne))
