@@ -363,8 +363,14 @@ ZC_DI fe fp_inverse_of_register(const fe& acc) { return fe_inverse_divsteps<FP>(
 // lo, lo + stride, lo + 2 stride, ...; see k_fe_invert_chunked in zc_kernels.hip.h: stride = number of
 // lanes, so that the lanes of a wave touch neighbouring records in every pass).
 // `num` != nullptr turns it into a batched division: out_j = num_j / a_j (Div, field.rs:277-300).
+// ILP: the chunk's multiplications on the independent-chain multiplier -- for launches that leave a single wave on a SIMD (2^20
+// elements at 16 per lane: BASELINE configs[1]), where nothing hides the column-ordered multiplier's serial chain: 0.0877 ->
+// 0.0815 ms per 2^20 inversions; with more waves per SIMD the column-ordered form is the faster one (2^24: 0.994 against 1.004
+// ms), so the host picks per launch (profiles/r06_experiments/fe_invert_ab.md).
+template <bool ILP = false>
 ZC_DI void fe_invert_chunk(const u64* a, u64* out, uint8_t* ok, size_t n, size_t lo, size_t stride, int c, const u64* num = nullptr)
 {
+    auto fp_mul = [](const fe& x, const fe& y) { return ILP ? mont_mul_ilp<FP>(x, y) : mont_mul<FP>(x, y); };
     const size_t avail = (n - lo + stride - 1) / stride;
     const int cnt = (int)(avail < (size_t)c ? avail : (size_t)c);
     const fe neutral = fe_one_m<FP>();

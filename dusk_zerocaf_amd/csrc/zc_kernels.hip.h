@@ -94,13 +94,13 @@ ZC_DI void add52(u64 (&r)[5], const u64 (&a)[5], const u64 (&b)[5], const u64 (&
 // per-lane kernel).
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-template <bool NT>
+template <bool NT, int THREADS = ZC_BLOCK>
 ZC_DI void coop_load40(u64* __restrict__ lds, const u64* __restrict__ g, int cnt)
 {
     const int nvec = (cnt * 5) >> 1;                       // 16-byte vectors
     const u64x2* gv = reinterpret_cast<const u64x2*>(g);
     u64x2* lv = reinterpret_cast<u64x2*>(lds);
-    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) lv[v] = NT ? __builtin_nontemporal_load(gv + v) : gv[v];
+    for (int v = threadIdx.x; v < nvec; v += THREADS) lv[v] = NT ? __builtin_nontemporal_load(gv + v) : gv[v];
     if ((cnt & 1) && threadIdx.x == 0) lds[cnt * 5 - 1] = g[cnt * 5 - 1];
 }
 template <bool NT>
@@ -227,6 +227,12 @@ ZC_KERNEL void k_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size_t n
     const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
     if (g < lanes) fe_invert_chunk(a, out, ok, n, g, lanes, c);
 }
+// the same for launches of at most one wave per SIMD (fe_invert_chunk<ILP>)
+ZC_KERNEL void k_fe_invert_chunked_lone(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
+{
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
+    if (g < lanes) fe_invert_chunk<true>(a, out, ok, n, g, lanes, c);
+}
 ZC_KERNEL void k_fe_sqrt_ratio_i(const u64* u, const u64* v, u64* out, uint8_t* was_square, size_t n)
 {
     const size_t i = gid();
@@ -252,6 +258,11 @@ ZC_KERNEL void k_fe_div_chunked(const u64* a, const u64* b, u64* out, uint8_t* o
 {
     const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
     if (g < lanes) fe_invert_chunk(b, out, ok, n, g, lanes, c, a);
+}
+ZC_KERNEL void k_fe_div_chunked_lone(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n, int c)
+{
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c, g = gid();
+    if (g < lanes) fe_invert_chunk<true>(b, out, ok, n, g, lanes, c, a);
 }
 ZC_KERNEL void k_fe_half(const u64* a, u64* out, size_t n)                          // field.rs:317-323
 {

@@ -53,6 +53,12 @@
 #ifndef ZC_MSM_SEG_QUAD
 #define ZC_MSM_SEG_QUAD 16384        // four lanes per segment in launches of at most this many segments
 #endif
+#ifndef ZC_MSM_EDGES_QUAD
+#define ZC_MSM_EDGES_QUAD 65536      // four lanes per run in the levels of the segmented reduction with at most this many runs (0: one lane; A/B)
+#endif
+#ifndef ZC_MSM_CARRY_PRESHIFT
+#define ZC_MSM_CARRY_PRESHIFT 1      // the lowest group's Horner rule takes the carry of the groups above already multiplied by 2^(c nw) (0: A/B)
+#endif
 #ifndef ZC_MSM_GROUP_LANES
 #define ZC_MSM_GROUP_LANES 17        // log2 of the lanes a window group's bucket-sum launch keeps busy
 #endif
@@ -142,34 +148,93 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
 // plain inverse of the register value).  A wave whose points all have Z = 1 (decompressed or already affine
 // inputs) skips the inversion.  Z = 0 (no point of the curve) takes the neutral value: garbage in, garbage out.
 constexpr int MSM_AFF_WORDS = 24;
-// All global traffic of the pass is coalesced: the workgroup's 256 consecutive point records of a step (40 KB) come in
-// through LDS with 16-byte loads (a lane reading its own 160-byte record from global memory issues twenty 8-byte loads on
-// two or three cache lines nobody else in its wave shares), the prefix products go out and come back as one 9 KB block
-// (parked in the records about to be written), and the finished 96-byte records leave through the same LDS buffer.
+// All global traffic of the pass is coalesced: the workgroup's consecutive point records of a step come in through LDS with
+// 16-byte loads (a lane reading its own 160-byte record from global memory issues twenty 8-byte loads on two or three cache
+// lines nobody else in its wave shares), the prefix products go out and come back as one block (parked in the records about
+// to be written), and the finished 96-byte records leave through the same LDS buffer.
+//
+// WORKGROUP = ONE WAVE (round 6).  Rounds 3-5 ran this pass in 256-thread workgroups: 49 KB of LDS each, three per CU = 150 of
+// the CU's 160 KB -- while they were resident no workgroup of the key sort's scatter kernels (41-51 KB) got on that CU, and the
+// two sides of the MSM's front matter took turns on the chip instead of sharing it (the limiter is LDS, not
+// the 86 VGPRs).  A wave stages its own 64 records (10 KB + 2.3 KB of prefixes = 12.3 KB), needs no workgroup barrier, and
+// the dispatcher can place normalisation waves beside one or two scatter workgroups on every CU.
+#ifndef ZC_MSM_PREP_BLOCK
+#define ZC_MSM_PREP_BLOCK 64         // threads per workgroup of k_msm_prepare_affine (A/B knob: 256 = rounds 3-5)
+#endif
+constexpr int MSM_PREP_BLOCK = ZC_MSM_PREP_BLOCK;
 ZC_DI void coop_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, int nvec)
 {
-    for (int v = threadIdx.x; v < nvec; v += ZC_BLOCK) dst[v] = src[v];
+    for (int v = threadIdx.x; v < nvec; v += MSM_PREP_BLOCK) dst[v] = src[v];
 }
 // `rec_words`: the record stride in 32-bit words -- 24 (records packed, 96 bytes: three of four straddle two 128-byte lines)
 // or 32 (one record per 128-byte line, a quarter of the array unused).
-ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c, u32 rec_words)
+// PREFETCH (round 6): a step is "load 10 KB, wait, a handful of multiplications, store" and a CU holds at most twelve such waves
+// (LDS), so the waves spent half their cycles waiting for their own loads.  The NEXT step's vectors are now requested into
+// registers (ten 16-byte vectors per lane + three of the prefix block) before the current step's arithmetic and moved to LDS
+// at the top of the next step; the first backward step is requested before the lane's inversion.
+#ifndef ZC_MSM_PREP_PREFETCH
+#define ZC_MSM_PREP_PREFETCH 1       // 0: A/B build that loads every step when it needs it (rounds 3-5)
+#endif
+extern "C" __global__ __launch_bounds__(ZC_MSM_PREP_BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
+void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c, u32 rec_words)
 {
-    __shared__ __attribute__((aligned(16))) u64 sp[ZC_BLOCK * 20];          // 256 point records in, 256 affine records out
-    __shared__ __attribute__((aligned(16))) u32 spre[ZC_BLOCK * 9];         // 256 prefix products
+    constexpr int NT = MSM_PREP_BLOCK;
+    constexpr int PV = (NT * 10 + NT - 1) / NT;                              // 16-byte vectors per lane of a block of NT point records (10)
+    constexpr int QV = (NT * 9 / 4 + NT - 1) / NT;                           // ... of a block of NT prefix products (3)
+    __shared__ __attribute__((aligned(16))) u64 sp[NT * 20];                // NT point records in, NT affine records out
+    __shared__ __attribute__((aligned(16))) u32 spre[NT * 9];               // NT prefix products
     const int t = threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * ZC_BLOCK;                      // lane g owns points g, g + stride, g + 2 stride, ...
-    const size_t first = (size_t)blockIdx.x * ZC_BLOCK;
+    const size_t stride = (size_t)gridDim.x * NT;                            // lane g owns points g, g + stride, g + 2 stride, ...
+    const size_t first = (size_t)blockIdx.x * NT;
     const fe neutral = fe_one_m<FP>();
     fe acc = neutral;
     bool all_one = true;
     int steps = 0;                                                           // steps of this workgroup (the same for all its lanes)
+    auto count_at = [&](size_t base) { return (int)(n - base < (size_t)NT ? n - base : (size_t)NT); };
+    // a block of point records: global -> registers (request) and registers -> LDS (land)
+    u64x2 pv[PV];
+    static_assert(QV == 3, "three prefix vectors per lane");
+    uint4 qv0, qv1, qv2;                                                     // (named: an array here ends up in scratch memory)
+    auto request_points = [&](size_t base, int cnt) {
+        const u64x2* gv = reinterpret_cast<const u64x2*>(points + 20 * base);
+#pragma unroll
+        for (int i = 0; i < PV; i++)
+            if (t + i * NT < cnt * 10) pv[i] = gv[t + i * NT];
+    };
+    auto land_points = [&](int cnt) {
+        u64x2* lv = reinterpret_cast<u64x2*>(sp);
+#pragma unroll
+        for (int i = 0; i < PV; i++)
+            if (t + i * NT < cnt * 10) lv[t + i * NT] = pv[i];
+    };
+    auto request_prefix = [&](size_t base, int cnt) {
+        const uint4* gv = reinterpret_cast<const uint4*>(recs + (size_t)rec_words * base);
+        const int nvec = (cnt * 9 + 3) / 4;
+        if (t < nvec) qv0 = gv[t];
+        if (t + NT < nvec) qv1 = gv[t + NT];
+        if (t + 2 * NT < nvec) qv2 = gv[t + 2 * NT];
+    };
+    auto land_prefix = [&](int cnt) {
+        uint4* lv = reinterpret_cast<uint4*>(spre);
+        const int nvec = (cnt * 9 + 3) / 4;
+        if (t < nvec) lv[t] = qv0;
+        if (t + NT < nvec) lv[t + NT] = qv1;
+        if (t + 2 * NT < nvec) lv[t + 2 * NT] = qv2;
+    };
+    if (ZC_MSM_PREP_PREFETCH && first < n) request_points(first, count_at(first));
     for (int j = 0; j < c; j++) {
         const size_t base = first + (size_t)j * stride;
         if (base >= n) break;
         steps = j + 1;
-        const int cnt = (int)(n - base < (size_t)ZC_BLOCK ? n - base : (size_t)ZC_BLOCK);
-        __syncthreads();
-        coop_load40<false>(sp, points + 20 * base, cnt * 4);
+        const int cnt = count_at(base);
+        __syncthreads();                                                     // (one wave per workgroup: no s_barrier is emitted, LDS operations of a wave execute in order)
+        if (ZC_MSM_PREP_PREFETCH) {
+            land_points(cnt);
+            const size_t nbase = base + stride;
+            if (j + 1 < c && nbase < n) request_points(nbase, count_at(nbase));     // in flight during this step's arithmetic
+        } else {
+            coop_load40<false, NT>(sp, points + 20 * base, cnt * 4);
+        }
         __syncthreads();
         if (t < cnt) {
             u64 l[5];
@@ -181,7 +246,7 @@ ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, i
             acc = fp_mul(acc, z);
         }
         __syncthreads();
-        // the step's prefix products wait in the first 9 KB of the 24 KB the step's records will occupy (whole 16-byte
+        // the step's prefix products wait at the start of the region the step's records will occupy (whole 16-byte
         // vectors: the tail of a partial block may run a few words into the next lane-less slots of the same region)
         coop_copy16(reinterpret_cast<uint4*>(recs + (size_t)rec_words * base), reinterpret_cast<const uint4*>(spre), (cnt * 9 + 3) / 4);
     }
@@ -193,15 +258,29 @@ ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, i
     if (!all_one) s_any = 1;
     __syncthreads();
     const bool skip = s_any == 0;
+    if (ZC_MSM_PREP_PREFETCH && steps > 0) {                                 // the last block again (the backward sweep starts there), under the inversion
+        const size_t base = first + (size_t)(steps - 1) * stride;
+        request_points(base, count_at(base));
+        if (!skip) request_prefix(base, count_at(base));
+    }
     fe inv = neutral;
     if (!skip) inv = fp_inverse_of_register(acc) , inv = fp_mul(inv, fe_const<FP>(ModP::R3));   // carries R^3 from here on: inv * pre = R^2 / Z
     const fe d2 = fe_const<FP>(ModP::D2_M);
     for (int j = steps - 1; j >= 0; j--) {
         const size_t base = first + (size_t)j * stride;
-        const int cnt = (int)(n - base < (size_t)ZC_BLOCK ? n - base : (size_t)ZC_BLOCK);
+        const int cnt = count_at(base);
         __syncthreads();
-        coop_load40<false>(sp, points + 20 * base, cnt * 4);
-        if (!skip) coop_copy16(reinterpret_cast<uint4*>(spre), reinterpret_cast<const uint4*>(recs + (size_t)rec_words * base), (cnt * 9 + 3) / 4);
+        if (ZC_MSM_PREP_PREFETCH) {
+            land_points(cnt);
+            if (!skip) land_prefix(cnt);
+            if (j > 0) {                                                     // the block below: always a full one
+                request_points(base - stride, NT);
+                if (!skip) request_prefix(base - stride, NT);
+            }
+        } else {
+            coop_load40<false, NT>(sp, points + 20 * base, cnt * 4);
+            if (!skip) coop_copy16(reinterpret_cast<uint4*>(spre), reinterpret_cast<const uint4*>(recs + (size_t)rec_words * base), (cnt * 9 + 3) / 4);
+        }
         __syncthreads();
         fe ymx, ypx, t2d;
         if (t < cnt) {
@@ -239,7 +318,7 @@ ZC_KERNEL_3W void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, i
             uint4* dst = reinterpret_cast<uint4*>(recs + (size_t)rec_words * base);
             const uint4* src = reinterpret_cast<const uint4*>(sp);
             const u32 rv = rec_words / 4;                       // 16-byte pieces per record slot: 6 (packed) or 8
-            for (int v = threadIdx.x; v < cnt * 6; v += ZC_BLOCK) dst[(size_t)(v / 6) * rv + (v % 6)] = src[v];
+            for (int v = threadIdx.x; v < cnt * 6; v += NT) dst[(size_t)(v / 6) * rv + (v % 6)] = src[v];
         }
     }
 }
@@ -422,15 +501,24 @@ void k_msm_runs_affine(const uint2* pairs, const u32* recs, u32 len, u32 T, u32 
 // Runs are shifted by one entry (run 0 = [0, T + 1), run j = [j T + 1, (j + 1) T + 1)): a bucket cut once
 // at the level above left its two edges in slots 2j + 1 and 2j + 2, and with an even T that pair always
 // lies inside one run here, so everything but the buckets longer than a run is finished at level 1.
-ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
-                                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+// QUAD: four lanes per run (pt_add_quad: three multiplication latencies per addition instead of nine, the same field values).
+// A level is a handful of dependent additions per lane on a list that fills a fraction of the chip: pure latency, and every
+// level of every window group lies on a chain -- the lowest group's on the call's critical path, the others' beside the
+// bucket sums of the groups below, which they hold up for as long as they run.  Every lane of a quad walks the same run
+// (quad-uniform control flow), lane 0 writes.
+template <bool QUAD>
+ZC_DI void msm_runs_edges_body(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                               u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
 {
     msm_tail_priority();
-    const u32 j = blockIdx.x * ZC_BLOCK + threadIdx.x;
+    const int role = QUAD ? (int)(threadIdx.x & 3) : 0;
+    const u32 j = QUAD ? blockIdx.x * (ZC_BLOCK / 4) + (threadIdx.x >> 2) : blockIdx.x * ZC_BLOCK + threadIdx.x;
     const u64 lo64 = j ? (u64)j * T + 1 : 0;
     if (lo64 >= len) return;
-    next_keys[2 * (size_t)j] = 0xFFFFFFFFu;
-    next_keys[2 * (size_t)j + 1] = 0xFFFFFFFFu;
+    if (role == 0) {
+        next_keys[2 * (size_t)j] = 0xFFFFFFFFu;
+        next_keys[2 * (size_t)j + 1] = 0xFFFFFFFFu;
+    }
     const u32 lo = (u32)lo64;
     const u64 hi64 = (u64)(j + 1) * T + 1;
     const u32 hi = hi64 < len ? (u32)hi64 : len;
@@ -455,16 +543,29 @@ ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T
     u32 cur_key = keys[lo];
     bool first = true;
     for (u32 e = lo; e < hi; e++) {
-        if (cur_key < nbuckets) acc = pt_add<true>(acc, pt_load_raw(recs + MSM_RAW_WORDS * (size_t)e));
+        if (cur_key < nbuckets) {
+            const pt rec = pt_load_raw(recs + MSM_RAW_WORDS * (size_t)e);
+            acc = QUAD ? pt_add_quad(acc, rec, role) : pt_add<true>(acc, rec);
+        }
         const bool last = e + 1 == hi;
         const u32 knext = last ? none : keys[e + 1];
         if (last || knext != cur_key) {
-            msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
+            if (role == 0) msm_flush(cur_key, acc, first, last, prev_key, next_key, j, nbuckets, buckets_raw, present, next_keys, next_recs);
             acc = pt_identity();
             first = false;
             cur_key = knext;
         }
     }
+}
+ZC_KERNEL void k_msm_runs_edges(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                                u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+{
+    msm_runs_edges_body<false>(keys, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs);
+}
+ZC_KERNEL void k_msm_runs_edges_quad(const u32* keys, const u32* recs, u32 len, u32 T, u32 nbuckets,
+                                     u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs)
+{
+    msm_runs_edges_body<true>(keys, recs, len, T, nbuckets, buckets_raw, present, next_keys, next_recs);
 }
 
 // One lane per segment of `seg` consecutive buckets [first, first + SEG) of one window (bucket
@@ -646,13 +747,16 @@ ZC_DI bool msm_is_literal_identity(const u64* s)
     for (int j = 0; j < 5; j++) nz |= s[j] | s[15 + j] | (s[5 + j] ^ s[10 + j]);
     return nz == 0;
 }
-ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c, const u64* carry)
+// `preshifted` != 0: `carry` already holds 2^(c W) * (the result of the groups above) -- k_msm_shift ran on the side stream as
+// soon as that result existed, beside the lowest group's bucket sums -- so the rule runs over this group's own windows only
+// and the carry is added last: c (W - 1) doublings on the call's critical path instead of c W.
+ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c, const u64* carry, int preshifted)
 {
     msm_tail_priority();
     const int role = threadIdx.x & 3;
     pt Q = pt_identity();
     bool started = false;
-    if (carry && !msm_is_literal_identity(carry)) {
+    if (carry && !preshifted && !msm_is_literal_identity(carry)) {
         Q = pt_load(carry);
         started = true;
     }
@@ -666,6 +770,20 @@ ZC_KERNEL void k_msm_window_combine(const u64* windows, u64* out, int W, int c, 
             started = true;
         }
     }
+    if (carry && preshifted && !msm_is_literal_identity(carry)) {
+        const pt S = pt_load(carry);
+        Q = started ? pt_add<true>(Q, S) : S;
+    }
+    if (threadIdx.x == 0) pt_store(out, Q);
+}
+// out = 2^k * in (k doublings on one quad of lanes; the literal identity stays what it is)
+ZC_KERNEL void k_msm_shift(const u64* in, u64* out, int k)
+{
+    msm_tail_priority();
+    const int role = threadIdx.x & 3;
+    pt Q = pt_load(in);
+    if (!msm_is_literal_identity(in))
+        for (int i = 0; i < k; i++) Q = pt_double_quad(Q, role);
     if (threadIdx.x == 0) pt_store(out, Q);
 }
 

@@ -42,6 +42,28 @@ ZC_DI ptm ptm_add_quad(const ptm& p, const ptm& q, int role)
     return r;
 }
 
+// The same step on (X, Y, Z, T) operands and with an (X, Y, Z, T) result -- pt_add's values (edwards.rs:465-489) -- for chains
+// whose intermediate sums live in memory in that form (the MSM's edge records, zc_msm.hip.h).
+ZC_DI pt pt_add_quad(const pt& p, const pt& q, int role)
+{
+    fe m1 = mont_mul_ilp<FP>(fe_by_role(role, fp_sub(p.Y, p.X), fe_add(p.Y, p.X), p.T, p.Z),
+                             fe_by_role(role, fp_sub(q.Y, q.X), fe_add(q.Y, q.X), fe_const<FP>(ModP::D_M), q.Z));
+    const fe c2 = mont_mul_ilp<FP>(m1, q.T);                 // used by lane 2 only
+    m1 = fe_select(role == 2, c2, m1);
+    const fe M = quad_bcast<0>(m1), P = quad_bcast<1>(m1), C = quad_bcast<2>(m1), D = quad_bcast<3>(m1);
+    const fe E = fe_sub_half<FP>(P, M);
+    const fe H = fp_sub(P, E);
+    const fe F = fp_sub(D, C);
+    const fe G = fe_add(D, C);
+    const fe m2 = mont_mul_ilp<FP>(fe_by_role(role, E, G, F, E), fe_by_role(role, F, H, G, H));
+    pt r;
+    r.X = quad_bcast<0>(m2);
+    r.Y = quad_bcast<1>(m2);
+    r.Z = quad_bcast<2>(m2);
+    r.T = quad_bcast<3>(m2);
+    return r;
+}
+
 // Strict scalar multiplication, four lanes per element (64 elements per workgroup): same loop and
 // same values as scalar_mul_unified, for batches of at most 2^14 elements.
 ZC_KERNEL void k_ed_scalar_mul_quad(const u64* p, const u64* k, u64* out, size_t n)

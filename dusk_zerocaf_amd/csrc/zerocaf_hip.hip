@@ -906,7 +906,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             int ac = (int)std::min<size_t>(16, std::max<size_t>(1, cnt >> 18));
             if (tune.msm_affine_chunk) ac = tune.msm_affine_chunk;
             const size_t lanes = (cnt + ac - 1) / ac;            // lane g owns points g, g + stride, ...: stride = the launch's lanes
-            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt, ac, rec_words);
+            hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3((unsigned)((lanes + zc::MSM_PREP_BLOCK - 1) / zc::MSM_PREP_BLOCK)), dim3(zc::MSM_PREP_BLOCK), 0, ps, dP, cached, cnt, ac, rec_words);
         } else {
             hipLaunchKernelGGL(aligned16(dP) ? zc::k_msm_prepare : zc::k_msm_prepare_lane, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, ps, dP, cached, cnt);
         }
@@ -963,8 +963,12 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                     const size_t nl = len <= t + 1 ? 1 : (len - 1 + t - 1) / t;
                     zc::u32* nk = ekeys[level & 1] + 2 * gr.slot0;
                     zc::u32* nr = erecs[level & 1] + 2 * gr.slot0 * zc::MSM_RAW_WORDS;
-                    hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, st, lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
-                                       buckets, present, nk, nr);
+                    if (nl <= (size_t)ZC_MSM_EDGES_QUAD)       // four lanes per run: the level is a few dependent additions on a fraction of the chip
+                        hipLaunchKernelGGL(zc::k_msm_runs_edges_quad, dim3(grid_for(4 * nl)), dim3(zc::ZC_BLOCK), 0, st, lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
+                                           buckets, present, nk, nr);
+                    else
+                        hipLaunchKernelGGL(zc::k_msm_runs_edges, dim3(grid_for(nl)), dim3(zc::ZC_BLOCK), 0, st, lk, lr, (zc::u32)len, (zc::u32)t, (zc::u32)nb,
+                                           buckets, present, nk, nr);
                     if (nl <= 1) break;                    // one lane saw the whole list: nothing is left open
                     if (level > 40) return fail(ZC_ERR_HIP, "zc_msm: segmented reduction did not converge");
                     lk = nk;
@@ -1000,8 +1004,15 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             // Horner's rule, top window first across the groups: this group continues from the result of the group above it
             // (same stream, or -- the lowest group -- behind that stream's event)
             if (g == G - 1 && G > 1 && ZC_MSM_TAIL_SIDE) HIP_TRY(hipStreamWaitEvent(st, D.ev_grp_done[G - 2], 0));
-            hipLaunchKernelGGL(zc::k_msm_window_combine, dim3(1), dim3(64), 0, st, (const u64*)cur, grp_out + 20 * (size_t)g, gr.nw, c,
-                               g > 0 ? (const u64*)(grp_out + 20 * (size_t)(g - 1)) : (const u64*)nullptr);
+            // The lowest group's stretch of the rule is on the call's critical path: it takes the result of the groups above ALREADY
+            // multiplied by 2^(c nw) -- k_msm_shift runs behind the second-lowest group's stretch on the side stream, beside the
+            // lowest group's bucket sums (slot G of grp_out) -- and adds it last.
+            const bool preshift = ZC_MSM_CARRY_PRESHIFT && G > 1 && ZC_MSM_TAIL_SIDE;
+            const bool lowest = g == G - 1;
+            const u64* carry = g == 0 ? nullptr : (lowest && preshift) ? grp_out + 20 * (size_t)G : grp_out + 20 * (size_t)(g - 1);
+            hipLaunchKernelGGL(zc::k_msm_window_combine, dim3(1), dim3(64), 0, st, (const u64*)cur, grp_out + 20 * (size_t)g, gr.nw, c, carry, lowest && preshift ? 1 : 0);
+            if (preshift && g == G - 2)
+                hipLaunchKernelGGL(zc::k_msm_shift, dim3(1), dim3(64), 0, st, (const u64*)(grp_out + 20 * (size_t)g), grp_out + 20 * (size_t)G, c * grp[G - 1].nw);
             if (st != D.s()) HIP_TRY(hipEventRecord(D.ev_grp_done[g], st));
         }
         *result = grp_out + 20 * (size_t)(G - 1);
@@ -1291,7 +1302,9 @@ int zc_fe_invert(zc_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* ok, siz
             hipLaunchKernelGGL(zc::k_fe_invert, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt);
         } else {
             const size_t lanes = (cnt + c - 1) / c;
-            hipLaunchKernelGGL(zc::k_fe_invert_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt, (int)c);
+            // at most one wave per SIMD (2^20 elements: BASELINE configs[1]): the independent-chain multiplier, -7 %
+            hipLaunchKernelGGL(lanes <= (size_t)D.cus * 256 ? zc::k_fe_invert_chunked_lone : zc::k_fe_invert_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(),
+                               (const u64*)d[0], (u64*)d[1], (uint8_t*)d[2], cnt, (int)c);
         }
     });
 }
@@ -1305,7 +1318,8 @@ int zc_fe_div(zc_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, 
             hipLaunchKernelGGL(zc::k_fe_div, dim3(grid_for(cnt)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt);
         } else {
             const size_t lanes = (cnt + c - 1) / c;
-            hipLaunchKernelGGL(zc::k_fe_div_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(), (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt, (int)c);
+            hipLaunchKernelGGL(lanes <= (size_t)D.cus * 256 ? zc::k_fe_div_chunked_lone : zc::k_fe_div_chunked, dim3(grid_for(lanes)), dim3(zc::ZC_BLOCK), 0, D.s(),
+                               (const u64*)d[0], (const u64*)d[1], (u64*)d[2], (uint8_t*)d[3], cnt, (int)c);
         }
     });
 }

@@ -199,6 +199,17 @@ extern "C" void emul_fe_invert_chunked(const u64* a, u64* out, uint8_t* ok, size
     const size_t lanes = (n + (size_t)c - 1) / (size_t)c;      // as k_fe_invert_chunked: lane g takes g, g + lanes, ...
     for (size_t g = 0; g < lanes; g++) fe_invert_chunk(a, out, ok, n, g, lanes, c);
 }
+// k_fe_invert_chunked_lone / k_fe_div_chunked_lone: the same on the independent-chain multiplier (launches of one wave per SIMD)
+extern "C" void emul_fe_invert_chunked_lone(const u64* a, u64* out, uint8_t* ok, size_t n, int c)
+{
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c;
+    for (size_t g = 0; g < lanes; g++) fe_invert_chunk<true>(a, out, ok, n, g, lanes, c);
+}
+extern "C" void emul_fe_div_chunked_lone(const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n, int c)
+{
+    const size_t lanes = (n + (size_t)c - 1) / (size_t)c;
+    for (size_t g = 0; g < lanes; g++) fe_invert_chunk<true>(b, out, ok, n, g, lanes, c, a);
+}
 // the MSM bucket accumulation's inner loop (zc_msm.hip.h): cached-operand additions on the
 // independent-chain multiplier, through the packed 128-byte record
 extern "C" void emul_bucket_sum(const u64* pts, size_t n, u64* out)

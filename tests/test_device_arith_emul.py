@@ -119,6 +119,11 @@ def test_emul_invert_sqrt_ratio(emul, oracle):
         emul.emul_fe_div_chunked(p(num), p(a2), p(out2), p(ok2), C.c_size_t(len(a2)), c)
         wq, wqok = oracle.fe_div(num, a2)
         assert np.array_equal(ok2, wqok) and np.array_equal(out2, wq), c
+        # the single-wave launches' form (independent-chain multiplier): k_fe_invert_chunked_lone / k_fe_div_chunked_lone
+        emul.emul_fe_invert_chunked_lone(p(a2), p(out2), p(ok2), C.c_size_t(len(a2)), c)
+        assert np.array_equal(ok2, wok2) and np.array_equal(out2, want2), c
+        emul.emul_fe_div_chunked_lone(p(num), p(a2), p(out2), p(ok2), C.c_size_t(len(a2)), c)
+        assert np.array_equal(ok2, wqok) and np.array_equal(out2, wq), c
     u = V.limbs_array(V.rand_fe(120, V.SEED + 4))
     v = V.limbs_array(list(reversed(V.rand_fe(120, V.SEED + 5))))
     sq = np.empty(len(u), dtype=np.uint8)

@@ -12,6 +12,7 @@ f=glob.glob('/tmp/tl/**/tl_kernel_trace.csv',recursive=True)[0]
 rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r["Start_Timestamp"]))
 starts=[i for i,r in enumerate(rows) if r["Kernel_Name"].startswith("k_msm_digits")]
 first=starts[-1]
+while first > 0 and rows[first - 1]["Kernel_Name"].startswith("k_msm_prepare"): first -= 1     # the normalisation is enqueued first, on its own stream
 seg=[r for r in rows[first:] if r["Kernel_Name"].startswith(("k_msm","k_scan","k_ed_scalar_mul","k_ed_add"))]
 last=max(i for i,r in enumerate(seg) if r["Kernel_Name"].startswith("k_msm_window_combine"))
 seg=seg[:last+1]
