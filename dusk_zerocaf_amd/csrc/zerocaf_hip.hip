@@ -901,9 +901,11 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             ps = D.aux;
         }
         if (affine) {
-            // points per lane of the normalisation: enough lanes for two to four waves per SIMD, enough points per
-            // lane to amortise its inversion (ZC_MSM_AFFINE_CHUNK overrides)
-            int ac = (int)std::min<size_t>(16, std::max<size_t>(1, cnt >> 18));
+            // points per lane of the normalisation: a CU holds twelve of its one-wave workgroups (LDS), so 2^17 lanes = 2048 waves are
+            // one round of resident waves with room left for the key sort beside them, and 8 - 16 points amortise the lane's
+            // inversion (round 6, prefetching kernel: 2^20 pairs 4 -> 8 per lane 2.30 -> 2.26 ms, 2^21 8 -> 16 3.34 -> 3.31, flat
+            // from 10 to 16; ZC_MSM_AFFINE_CHUNK overrides)
+            int ac = (int)std::min<size_t>(16, std::max<size_t>(1, cnt >> 17));
             if (tune.msm_affine_chunk) ac = tune.msm_affine_chunk;
             const size_t lanes = (cnt + ac - 1) / ac;            // lane g owns points g, g + stride, ...: stride = the launch's lanes
             hipLaunchKernelGGL(zc::k_msm_prepare_affine, dim3((unsigned)((lanes + zc::MSM_PREP_BLOCK - 1) / zc::MSM_PREP_BLOCK)), dim3(zc::MSM_PREP_BLOCK), 0, ps, dP, cached, cnt, ac, rec_words);
