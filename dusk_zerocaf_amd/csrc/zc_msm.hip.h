@@ -51,8 +51,11 @@
 #define ZC_MSM_FOLD_QUAD 1           // the fold tree with four lanes per addition (0: one lane, 512 points per workgroup)
 #endif
 #ifndef ZC_MSM_SEG_QUAD
-#define ZC_MSM_SEG_QUAD 16384        // four lanes per segment in launches of at most this many segments
+#define ZC_MSM_SEG_QUAD 16384        // four lanes per segment in launches of at most this many segments (twice as many for the lowest of several window groups)
 #endif
+#ifndef ZC_MSM_LOW_SEG_HALF
+#define ZC_MSM_LOW_SEG_HALF 0        // 1: the lowest window group reduces its buckets in segments of half the length.  Round 6, measured and not
+#endif                               // taken: 39 instead of 54 dependent additions, but twice the quads -- k_msm_segments_quad 150 -> 194 us at 2^21 pairs
 #ifndef ZC_MSM_EDGES_QUAD
 #define ZC_MSM_EDGES_QUAD 65536      // four lanes per run in the levels of the segmented reduction with at most this many runs (0: one lane; A/B)
 #endif

@@ -740,6 +740,7 @@ struct MsmPlan {
     int rec_bytes = 128;           // stride of the cached records (affine: 96 packed or 128 = one per cache line; projective: 128)
     int G = 1;                     // window groups, top windows first: gw[g] windows, run length gT[g]
     int gw[4] = {0, 0, 0, 0}, gT[4] = {0, 0, 0, 0};
+    int gseg[4] = {0, 0, 0, 0};    // buckets per reduction segment, per group (the lowest group's chain is exposed: shorter segments)
     int bad_groups = 0;            // ZC_MSM_GROUPS was given and adds up to this many windows instead of W: the call fails
     MsmSortPlan sort;
 };
@@ -800,6 +801,15 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     // 3.71 / 3.48 / 3.61 / 4.30 ms: shorter runs cut more buckets, and every cut is an edge for the levels behind)
     for (int g = 0; g < p.G; g++)
         p.gT[g] = p.G == 1 ? p.T : msm_run_length(cnt * (size_t)p.gw[g], tune, ZC_MSM_GROUP_LANES);
+    // Segment length per group.  (ZC_MSM_LOW_SEG_HALF: half the length for the lowest group, whose chain is on the call's critical
+    // path -- 39 instead of 54 dependent additions; measured in round 6 and not taken, the segments are not pure latency.)
+    for (int g = 0; g < p.G; g++) {
+        p.gseg[g] = p.seg;
+        const size_t nsegg2 = 2 * (size_t)p.gw[g] * (((size_t)1 << (p.c - 1)) / (size_t)p.seg);
+        if (ZC_MSM_LOW_SEG_HALF && p.G > 1 && g == p.G - 1 && !tune.msm_seg && p.seg >= 4 && nsegg2 <= 2 * (size_t)ZC_MSM_SEG_QUAD) p.gseg[g] = p.seg / 2;
+    }
+    p.nseg = 0;
+    for (int g = 0; g < p.G; g++) p.nseg += (size_t)p.gw[g] * (((size_t)1 << (p.c - 1)) / (size_t)p.gseg[g]);
     return p;
 }
 
@@ -826,7 +836,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         snprintf(msg, sizeof msg, "zc_msm: ZC_MSM_GROUPS adds up to %d windows, a shard of %zu pairs has %d (%d-bit windows)", mp.bad_groups, cnt, mp.W, mp.c);
         return fail(ZC_ERR_BAD_ARG, msg);
     }
-    const int c = mp.c, W = mp.W, seg = mp.seg, TE = mp.TE;
+    const int c = mp.c, W = mp.W, TE = mp.TE;
     const size_t m = mp.m, nb = mp.nb, nseg = mp.nseg;
     if (m > 0xFFFFFFFFull) return fail(ZC_ERR_BAD_ARG, "zc_msm: shard too large for 32-bit pair indices");
     const MsmSortPlan& plan = mp.sort;
@@ -864,7 +874,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             grp[g].st = g == G - 1 ? D.s() : D.grp;          // ONE side stream: streams of one priority share a hardware queue here anyway
         }
     }
-    const size_t spw = ((size_t)1 << (c - 1)) / (size_t)seg;   // segments per window (both powers of two)
+    size_t seg_off[5] = {0, 0, 0, 0, 0};                        // group g's part of the segment arrays (segments per window: a power of two per group)
+    for (int g = 0; g < G; g++) seg_off[g + 1] = seg_off[g] + (size_t)grp[g].nw * (((size_t)1 << (c - 1)) / (size_t)mp.gseg[g]);
     const zc::u32 rec_words = affine ? (zc::u32)(mp.rec_bytes / 4) : 32u;
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? (char*)D.msm : nullptr};
@@ -929,7 +940,8 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
         for (int g = 0; g < G; g++) {
             Group& gr = grp[g];
             const size_t b0 = (size_t)gr.w0 << (c - 1);                  // the group's first bucket
-            const size_t nsegg = (size_t)gr.nw * spw;
+            const int seg = mp.gseg[g];
+            const size_t nsegg = seg_off[g + 1] - seg_off[g];
             // A launch that runs beside the chain of the group above it leaves that chain room: its workgroups are padded with
             // dynamic LDS so that only `wgs` of them fit a CU (three: one wave slot per SIMD, 200 VGPRs and 39 KB of LDS stay free;
             // a chain kernel that finds every slot taken waits for a bucket-sum workgroup to retire).
@@ -979,10 +991,10 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
                 }
             }
             // bucket reduction: one lane per segment -> sum_j (first' + j + 1) B_(first + j), the product by first' included
-            u64* cur = seg_out + 20 * (size_t)gr.w0 * spw;
-            u64* nxt = fold_b + 20 * (size_t)gr.w0 * spw;
+            u64* cur = seg_out + 20 * seg_off[g];
+            u64* nxt = fold_b + 20 * seg_off[g];
             // few segments (the lowest group, small shards): four lanes per segment, three multiplication latencies per addition
-            const size_t quad_max = (size_t)ZC_MSM_SEG_QUAD;
+            const size_t quad_max = (size_t)ZC_MSM_SEG_QUAD * (G > 1 && g == G - 1 ? 2 : 1);     // (the exposed chain: lanes for latency)
             if (nsegg <= quad_max)
                 hipLaunchKernelGGL(zc::k_msm_segments_quad, dim3((unsigned)((nsegg + 63) / 64)), dim3(zc::ZC_BLOCK), 0, st, (const zc::u32*)(buckets + b0 * zc::MSM_RAW_WORDS),
                                    (const uint8_t*)(present + b0), cur, nsegg, c, seg);
