@@ -701,12 +701,18 @@ def self_launch(args, json_fd):
         if have < n:
             raise SystemExit("bench.py: --gpus %d but %d visible device%s: refusing to time fewer GPUs than asked for"
                              % (n, have, "" if have == 1 else "s"))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # What the ranks inherit can be overridden from the caller's environment (none of it has met a
+    # second GPU yet): MASTER_ADDR / MASTER_PORT when set (default: 127.0.0.1 and a free port), HSA_ENABLE_IPC_MODE_LEGACY when
+    # set (default 0: this image's host driver only supports dmabuf IPC, RCCL's device-memory exchange fails without it).
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR=addr,
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE if r == 0 else 2, stderr=2))
