@@ -1143,6 +1143,28 @@ def test_msm_degenerate_scalars(eng, oracle):
     assert eq(oracle.ed_compress(eng.msm(P, K))[0], oracle.ed_compress(_gpu_naive_msm(eng, P, K))[0])
 
 
+def test_msm_window_groups_with_empty_groups(oracle):
+    """Window groups and the pre-shifted carry (k_msm_shift, round 6): the lowest group adds 2^(c nw) x (the result of the groups
+    above) LAST.  Degenerate splits of a 6000-pair shard (c = 8: 33 windows): scalars below 2^15 leave every upper group empty (the
+    carry is the literal identity and must stay it through the shift), scalars that are multiples of 2^200 leave the lowest groups
+    empty (the rule starts from nothing and the carry is the whole result), and both kinds mixed -- against the oracle's sum."""
+    n = 6000
+    P = np.tile(V.base_multiples(oracle, 1024, V.SEED + 186), (6, 1))[:n].copy()
+    rng = np.random.default_rng(V.SEED + 187)
+    low = np.zeros((n, 5), dtype=np.uint64)
+    low[:, 0] = rng.integers(0, 1 << 15, size=n, dtype=np.uint64)                  # two windows, no carry beyond them
+    high = np.zeros((n, 5), dtype=np.uint64)
+    high[:, 3] = rng.integers(0, 256, size=n, dtype=np.uint64) << np.uint64(44)    # bits 200 and up only
+    high[:, 4] = rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+    mixed = np.where((np.arange(n) % 2 == 0)[:, None], low, high)
+    for groups in ("30,3", "20,10,3", "10,10,10,3", "31,2"):
+        with V.tuned(ZC_MSM_GROUPS=groups, ZC_MSM_WINDOW=8) as te:
+            assert te.msm_plan(n)["window_groups"] == len(groups.split(",")), groups
+            for K in (low, high, mixed):
+                got, want = te.msm(P, K), oracle.msm_naive_mt(P, K)
+                assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0]), groups
+
+
 def _msm_sort_model(K, c, groups=None):
     """numpy model of k_msm_digits + the bucket sort: pairs (window << (c-1) | |d| - 1, i | sign << 31) in
     stable bucket order, the zero digits (key 0xFFFFFFFF) behind every bucket, window by window.
