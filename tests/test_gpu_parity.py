@@ -1143,6 +1143,32 @@ def test_msm_degenerate_scalars(eng, oracle):
     assert eq(oracle.ed_compress(eng.msm(P, K))[0], oracle.ed_compress(_gpu_naive_msm(eng, P, K))[0])
 
 
+def test_msm_normalisation_skips_the_inversion_for_affine_inputs(eng, oracle):
+    """k_msm_prepare_affine: a wave whose 64 x c points all have Z = 1 (decompressed or already affine inputs) needs no inversion and
+    requests no prefix block (round 6: the prefetching form).  All-affine input, and input whose first half is affine and second
+    half projective (waves of both kinds and, with the lane's points 2^17 lanes apart, waves that mix them), at 2^17 + 77 pairs
+    (ragged last block), default and forced points-per-lane: against the oracle's sum."""
+    n = (1 << 17) + 77
+    Pp = eng.ed_mul_base(V.rand_scalars_np(n, V.SEED + 430, bits=249))
+    xy, ok = eng.ed_to_affine(Pp)
+    assert ok.all()
+    Pa = np.zeros_like(Pp)
+    Pa[:, 0:5], Pa[:, 5:10] = xy[:, 0:5], xy[:, 5:10]
+    Pa[:, 10] = 1
+    Pa[:, 15:20] = eng.fe_mul(np.ascontiguousarray(xy[:, 0:5]), np.ascontiguousarray(xy[:, 5:10]))
+    assert oracle.ed_is_valid(Pa[:2000]).all() and eng.ed_eq(Pa, Pp).all()
+    K = V.rand_scalars_np(n, V.SEED + 431, bits=252)
+    mixed = Pa.copy()
+    mixed[n // 2:] = Pp[n // 2:]
+    for P in (Pa, mixed):
+        want = oracle.msm_naive_mt(P, K)
+        for chunk in (None, 1, 2, 7):
+            with V.tuned(hooks=chunk is not None, ZC_MSM_AFFINE_CHUNK=chunk) as te:
+                assert te.msm_plan(n)["affine"]
+                got = te.msm(P, K)
+            assert oracle.ed_eq(got, want)[0] == 1 and eq(oracle.ed_compress(got)[0], oracle.ed_compress(want)[0]), chunk
+
+
 def test_msm_window_groups_with_empty_groups(oracle):
     """Window groups and the pre-shifted carry (k_msm_shift, round 6): the lowest group adds 2^(c nw) x (the result of the groups
     above) LAST.  Degenerate splits of a 6000-pair shard (c = 8: 33 windows): scalars below 2^15 leave every upper group empty (the
