@@ -410,7 +410,7 @@ def roofline_for(env, run, kern_avg_s):
             measured["frac_issued"] = round(roofline["issued"]["achieved"] / measured["v_mad_u64_u32_T_lane_ops_per_s"], 4)
     if wl == "msm" and digits is not None:
         # the gathers of the bucket sums: one cached record per non-zero digit, random over the record array
-        rec = plan["record_bytes"]                   # the payload a gather requests (96 affine / 128 projective); the stride is what it touches
+        rec = plan["record_bytes"]                   # the payload a gather requests (112 affine: 27 limb words in seven 16-byte pieces / 128 projective); the stride is what it touches
         g = {"record_bytes": rec, "record_stride_bytes": plan["record_stride"], "records": digits, "unit": "GB/s", "peak": HBM_COPY_GBS,
              "peak_basis": "what a device copy reaches (MI355X_MICROARCH.md); random %d-byte gathers, one per %d-byte slot" % (rec, plan["record_stride"])}
         runs = (kin.get("runs") or {}).get(str(n))

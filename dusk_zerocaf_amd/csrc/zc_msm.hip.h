@@ -12,7 +12,7 @@
 //                       window << (c-1) | |d| - 1, point index | sign << 31) ordered by bucket, zero
 //                       digits (key 0xFFFFFFFF) behind every bucket
 //   0. k_msm_prepare  : points -> cached form, Montgomery domain.  Large batches: AFFINE records
-//                       (y-x, y+x, 2dxy), 96 bytes of payload at a 128-byte stride (one record per cache line), one
+//                       (y-x, y+x, 2dxy) as 27 limb words (gathered as 112 bytes) at a 128-byte stride (one record per cache line), one
 //                       division-step inversion per lane shared by its points (Montgomery's trick), so that a bucket
 //                       addition costs 7 multiplications; small batches: (Y-X, Y+X, Z, 2dT), 128 bytes, 8 multiplications
 //   3. k_msm_runs     : the bucket sums as a SEGMENTED REDUCTION of the sorted list in fixed-length
@@ -22,7 +22,7 @@
 //                       with n / 2^k points each; one lane per bucket would serialise them).  A bucket
 //                       that lies inside one run is written out directly; a bucket that crosses run
 //                       boundaries leaves one partial sum per run ("edge"), and the edge list -- again
-//                       sorted by key, 2 n W / T entries -- goes through k_msm_runs_edges level by level until
+//                       sorted by key, 2 n W / T entries -- goes through k_msm_runs_edges(_quad) level by level until
 //                       one lane holds it all (list lengths shrink by 4 per level).  Each point costs one mixed
 //                       addition against the cached record (negated by swapping Y-X / Y+X and negating 2dT when the
 //                       digit is negative); the next record is prefetched straight into LDS (global_load_lds), four
@@ -34,7 +34,7 @@
 //                       (k_msm_segments_quad: four lanes per segment for launches of few segments)
 //   5. k_msm_fold_groups : the segment sums of every window down to one point per window (LDS tree, two launches)
 //   6. k_msm_window_combine : sum_w 2^(c w) S_w by Horner's rule, one quad of lanes per doubling, continued from the
-//                       result of the window group above
+//                       result of the window group above (the lowest group: from k_msm_shift's pre-multiplied copy of it)
 #pragma once
 #include "zc_kernels.hip.h"
 #include "zc_quad.hip.h"
@@ -68,10 +68,13 @@
 #ifndef ZC_MSM_GROUP_WGS
 #define ZC_MSM_GROUP_WGS 3           // workgroups per CU of the bucket-sum launches that run beside a chain (0: no limit)
 #endif
+#ifndef ZC_MSM_AFF_LIMBS
+#define ZC_MSM_AFF_LIMBS 1           // affine records hold the kernels' own 29-bit limbs (3 x 9 words = 108 bytes, gathered as 112) instead of three packed
+#endif                               // 256-bit words (96 bytes): the bucket sums skip 3 x 9 limb extractions (64-bit shifts) per addition; same cache line
 #ifndef ZC_MSM_REC_STRIDE
-#define ZC_MSM_REC_STRIDE 128        // stride of the 96-byte affine records: 128 = one per cache line, 96 = packed
+#define ZC_MSM_REC_STRIDE 128        // stride of the affine records: 128 = one per cache line, 96 = packed (packed 256-bit-word records only)
 #endif
-static_assert(ZC_MSM_REC_STRIDE == 96 || ZC_MSM_REC_STRIDE == 128, "ZC_MSM_REC_STRIDE");
+static_assert(ZC_MSM_REC_STRIDE == 128 || (ZC_MSM_REC_STRIDE == 96 && !ZC_MSM_AFF_LIMBS), "ZC_MSM_REC_STRIDE");
 #ifndef ZC_MSM_ACC_ILP
 #define ZC_MSM_ACC_ILP false   // bucket sums on the column-ordered multiplier: with fixed-length runs every wave has
                                // three neighbours to overlap with (2^24 pairs: 25.1 -> 24.7 ms against the
@@ -142,7 +145,7 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
     const int t = threadIdx.x;
     if (t < cnt) niels_store(cached + 32 * (base + t), niels_from_pt(pt_load(sp + 20 * t)));
 }
-// AFFINE records (large batches): (y - x, y + x, 2 d x y) as 3 x 256-bit words = 96 bytes, Montgomery domain; the
+// AFFINE records (large batches): (y - x, y + x, 2 d x y), Montgomery domain, as 3 x 9 limb words (ZC_MSM_AFF_LIMBS; rounds 3-5: as 3 x 256-bit words = 96 bytes); the
 // bucket additions then skip Z Z' (pt_add_cached<., AFFINE>: 7 multiplications instead of 8) and gather 96
 // bytes instead of 128.  One lane normalises the points lo, lo + stride, ... (at most c; stride = number of
 // lanes, so a wave touches neighbouring records in every pass) with ONE division-step inversion: Montgomery's
@@ -150,11 +153,12 @@ ZC_KERNEL void k_msm_prepare(const u64* points, u32* cached, size_t n)
 // written (as ed_to_affine_chunk: plain limbs serve as Montgomery residues, fp_inverse_of_register returns the
 // plain inverse of the register value).  A wave whose points all have Z = 1 (decompressed or already affine
 // inputs) skips the inversion.  Z = 0 (no point of the curve) takes the neutral value: garbage in, garbage out.
-constexpr int MSM_AFF_WORDS = 24;
+constexpr int MSM_AFF_WORDS = ZC_MSM_AFF_LIMBS ? 28 : 24;      // 32-bit words of a record as it is gathered (limb records: 27 used)
+constexpr int MSM_AFF_PIECES = MSM_AFF_WORDS / 4;              // ... in 16-byte pieces
 // All global traffic of the pass is coalesced: the workgroup's consecutive point records of a step come in through LDS with
 // 16-byte loads (a lane reading its own 160-byte record from global memory issues twenty 8-byte loads on two or three cache
 // lines nobody else in its wave shares), the prefix products go out and come back as one block (parked in the records about
-// to be written), and the finished 96-byte records leave through the same LDS buffer.
+// to be written), and the finished records leave through the same LDS buffer.
 //
 // WORKGROUP = ONE WAVE (round 6).  Rounds 3-5 ran this pass in 256-thread workgroups: 49 KB of LDS each, three per CU = 150 of
 // the CU's 160 KB -- while they were resident no workgroup of the key sort's scatter kernels (41-51 KB) got on that CU, and the
@@ -312,16 +316,26 @@ void k_msm_prepare_affine(const u64* points, u32* recs, size_t n, int c, u32 rec
         __syncthreads();                                        // every lane has read its point: the buffer takes the records
         if (t < cnt) {
             u32* o = reinterpret_cast<u32*>(sp) + MSM_AFF_WORDS * t;
-            pack256(o, ymx);
-            pack256(o + 8, ypx);
-            pack256(o + 16, t2d);
+            if (ZC_MSM_AFF_LIMBS) {                             // the limbs as they are: ymx / ypx normalized, t2d R-class (every limb < 2^29 ... 2^30)
+#pragma unroll
+                for (int w = 0; w < 9; w++) {
+                    o[w] = ymx.v[w];
+                    o[9 + w] = ypx.v[w];
+                    o[18 + w] = t2d.v[w];
+                }
+                o[27] = 0;
+            } else {
+                pack256(o, ymx);
+                pack256(o + 8, ypx);
+                pack256(o + 16, t2d);
+            }
         }
         __syncthreads();
         {
             uint4* dst = reinterpret_cast<uint4*>(recs + (size_t)rec_words * base);
             const uint4* src = reinterpret_cast<const uint4*>(sp);
             const u32 rv = rec_words / 4;                       // 16-byte pieces per record slot: 6 (packed) or 8
-            for (int v = threadIdx.x; v < cnt * 6; v += NT) dst[(size_t)(v / 6) * rv + (v % 6)] = src[v];
+            for (int v = threadIdx.x; v < cnt * MSM_AFF_PIECES; v += NT) dst[(size_t)(v / MSM_AFF_PIECES) * rv + (v % MSM_AFF_PIECES)] = src[v];
         }
     }
 }
@@ -424,7 +438,7 @@ template <bool AFFINE>
 ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict__ recs, u32 len, u32 T, u32 nbuckets,
                          u32* buckets_raw, uint8_t* present, u32* next_keys, u32* next_recs, const u32* range_lo, const u32* range_end, u32 j, u32 sj, u32 rec_words)
 {
-    constexpr int PIECES = AFFINE ? 6 : 8;                     // 16-byte pieces of a cached record
+    constexpr int PIECES = AFFINE ? MSM_AFF_PIECES : 8;        // 16-byte pieces of a cached record
     __shared__ uint4 stage[PIECES * MSM_RUN_BLOCK];
     const int lane = threadIdx.x & 63;
     uint4* base = stage + (threadIdx.x >> 6) * (PIECES * 64);
@@ -458,6 +472,21 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
     for (u32 e = lo; e < hi; e++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         niels q;
+        if (AFFINE && ZC_MSM_AFF_LIMBS) {
+            u32 w[28];
+#pragma unroll
+            for (int p7 = 0; p7 < 7; p7++) {
+                const uint4 x = base[p7 * 64 + lane];
+                w[4 * p7] = x.x; w[4 * p7 + 1] = x.y; w[4 * p7 + 2] = x.z; w[4 * p7 + 3] = x.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                q.ymx.v[k] = w[k];
+                q.ypx.v[k] = w[9 + k];
+                q.t2d.v[k] = w[18 + k];
+            }
+            q.z = fe_zero();                                   // unused: Z' = 1
+        } else {
         q.ymx = unpack256(base[0 * 64 + lane], base[1 * 64 + lane]);
         q.ypx = unpack256(base[2 * 64 + lane], base[3 * 64 + lane]);
         if (AFFINE) {
@@ -466,6 +495,7 @@ ZC_DI void msm_runs_body(const uint2* __restrict__ pairs, const u32* __restrict_
         } else {
             q.z = unpack256(base[4 * 64 + lane], base[5 * 64 + lane]);
             q.t2d = unpack256(base[(PIECES - 2) * 64 + lane], base[(PIECES - 1) * 64 + lane]);
+        }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool neg = (vcur >> 31) != 0;

@@ -62,7 +62,7 @@ struct Tuning {
     long inv_chunk = 0;              // ZC_INV_CHUNK=c (1..64): elements per lane sharing one inversion
     int jacobi_rounds = -1;          // ZC_JACOBI_ROUNDS=r (0..200): rounds before legendre_symbol falls back to the power
     int msm_window = 0;              // ZC_MSM_WINDOW=c
-    int msm_affine = -1;             // ZC_MSM_AFFINE=0/1: projective 128-byte records / affine 96-byte records whatever the shard size
+    int msm_affine = -1;             // ZC_MSM_AFFINE=0/1: projective 128-byte records / affine 112-byte records whatever the shard size
     int msm_groups[4] = {0, 0, 0, 0};   // ZC_MSM_GROUPS="a,b[,c[,d]]": windows per group, top group first ("1" = one group)
     int msm_ngroups = 0;
     // ---- test-hooks build only
@@ -719,7 +719,7 @@ int msm_sort(DevState& D, hipStream_t st, const MsmSortPlan& pl, int w0, int nw,
     return ZC_OK;
 }
 
-// Affine cached records (7-multiplication bucket additions, 96-byte gathers) from this many points on: the
+// Affine cached records (7-multiplication bucket additions, 112-byte gathers) from this many points on: the
 // normalisation costs one division-step inversion per lane, which small batches cannot amortise.
 // ZC_MSM_AFFINE=0/1 forces the choice (tests, A/B).
 constexpr size_t MSM_AFFINE_MIN_N = (size_t)1 << 17;
@@ -733,7 +733,7 @@ inline bool msm_affine(size_t cnt, const Tuning& tune)
 struct MsmPlan {
     bool buckets = false;          // false: below MSM_BUCKET_MIN_N -- n scalar multiplications + pairwise folds
     int c = 0, W = 0;              // window bits, windows
-    bool affine = false;           // 96-byte affine records + 7-multiplication additions (else 128-byte projective, 8)
+    bool affine = false;           // affine records (27 limb words) + 7-multiplication additions (else 128-byte projective, 8)
     int T = 0, TE = 0;             // run lengths of the segmented reduction: level 0, deeper levels
     int seg = 0;                   // buckets per reduction segment
     size_t m = 0, nb = 0, nseg = 0;   // list entries (n W), buckets, segments
@@ -768,7 +768,7 @@ MsmPlan msm_plan(size_t cnt, bool points_aligned16, const Tuning& tune)
     p.nseg = p.nb / (size_t)p.seg;
     p.sort = msm_sort_plan(cnt, p.c, p.W, tune);
     p.affine = msm_affine(cnt, tune) && points_aligned16;  // the normalisation moves the point records with 16-byte loads
-    // affine records: 96 bytes of payload at a 128-byte stride -- one record per cache line.  Packed (96-byte stride) three records
+    // affine records: 108 bytes of payload (rounds 3-5: 96) at a 128-byte stride -- one record per cache line.  Packed (96-byte stride) three records
     // of four straddle two lines: measured (rocprofv3 TCC_EA0_RDREQ of k_msm_runs_affine, profiles/r04_msm_record_stride.md)
     // 34.6 -> 25.1 read requests per pair at 2^21 pairs, 34.3 -> 27.7 at 2^24; 2^21: 3.50 -> 3.50 ms, 2^22: 6.30 -> 6.13, 2^24: 21.18 -> 20.22.
     p.rec_bytes = p.affine ? ZC_MSM_REC_STRIDE : 128;
@@ -948,7 +948,7 @@ int msm_on_device(DevState& D, const u64* dP, const u64* dK, size_t cnt, const u
             size_t pad = 0;
             if (g > 0) {
                 const long wgs = ZC_MSM_GROUP_WGS;
-                const size_t own = (affine ? 6 : 8) * 16 * (size_t)zc::MSM_RUN_BLOCK;       // the kernel's static staging area
+                const size_t own = (affine ? zc::MSM_AFF_PIECES : 8) * 16 * (size_t)zc::MSM_RUN_BLOCK;       // the kernel's static staging area
                 if (wgs > 0 && (size_t)(wgs + 1) * own <= 163840) {
                     const size_t per = 163840 / (size_t)(wgs + 1) + 512;                     // wgs + 1 of these do not fit 160 KB
                     pad = per > own ? std::min<size_t>(per - own, 65536 - own) : 0;
@@ -1886,7 +1886,7 @@ long long zc_test_staged_launches(zc_ctx* ctx)
 // work.  A measurement aid: a roofline record counts the useful multiplications from c, W and the addition formula.
 // Writes min(nout, 17) entries (nout >= 8): [0] window bits c (0: below the bucket threshold, n scalar multiplications + folds),
 // [1] windows W, [2] 1 = affine records / 7-multiplication additions, 0 = projective / 8, [3] PAYLOAD bytes of a gathered
-// record (96 / 128), [4] run length of the bucket-sum kernel (window groups: the top group's), [5] buckets per reduction
+// record (112 / 128), [4] run length of the bucket-sum kernel (window groups: the top group's), [5] buckets per reduction
 // segment, [6] sort passes, [7] window groups G, [8] record STRIDE in bytes (what a gather touches: one 128-byte line),
 // [9..12] windows per group (top group first), [13..16] run length per group.
 int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out, int nout)
@@ -1897,7 +1897,7 @@ int zc_msm_plan(zc_ctx* ctx, size_t n, int points_aligned16, int32_t* out, int n
     const MsmPlan p = msm_plan(n, points_aligned16 != 0, ctx->devs[0].tune);
     if (p.bad_groups) return fail(ZC_ERR_BAD_ARG, "zc_msm_plan: ZC_MSM_GROUPS does not add up to this shard's window count");
     const bool b = p.buckets;
-    const int32_t v[17] = {p.c, p.W, p.affine ? 1 : 0, b ? (p.affine ? 96 : 128) : 0, b ? p.gT[0] : 0, p.seg, p.sort.passes, b ? p.G : 0, b ? p.rec_bytes : 0,
+    const int32_t v[17] = {p.c, p.W, p.affine ? 1 : 0, b ? (p.affine ? zc::MSM_AFF_WORDS * 4 : 128) : 0, b ? p.gT[0] : 0, p.seg, p.sort.passes, b ? p.G : 0, b ? p.rec_bytes : 0,
                            p.gw[0], p.gw[1], p.gw[2], p.gw[3], p.gT[0], p.gT[1], p.gT[2], p.gT[3]};
     memcpy(out, v, sizeof(int32_t) * (size_t)std::min(nout, 17));
     return ZC_OK;

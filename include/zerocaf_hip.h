@@ -255,7 +255,7 @@ int zc_msm(zc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, size_t 
  *   zc_msm_plan         a query, no device work: what the bucket method would do for a shard of n pairs on this
  *                       context.  Writes min(nout, 17) entries, nout >= 8: {window bits c (0: below the bucket
  *                       threshold, n scalar multiplications + folds), windows W, 1 = affine records and
- *                       7-multiplication additions / 0 = projective and 8, PAYLOAD bytes of a gathered record (96 /
+ *                       7-multiplication additions / 0 = projective and 8, PAYLOAD bytes of a gathered record (112 /
  *                       128), run length of the bucket-sum kernel (window groups: the top group's), buckets per
  *                       reduction segment, sort passes, window groups G, record STRIDE in bytes, windows per group
  *                       [4] (top group first), run length per group [4]}.  What a roofline record counts its useful
