@@ -128,7 +128,7 @@ int main()
     CHECK(Backend::slot_count() == 1 && Backend::device(0) >= 0 && Backend::device(0) < Backend::device_count());     // what zc_ctx_create(NULL, 0) picked
     {
         const auto plan = msm_plan(1 << 21);                  // the library's own plan for a config-5 shard: three window groups that add up
-        CHECK(plan[0] == 17 && plan[1] == 16 && plan[7] == 3 && plan[9] + plan[10] + plan[11] == 16 && plan[3] == 96 && plan[8] == 128);
+        CHECK(plan[0] == 17 && plan[1] == 16 && plan[7] == 3 && plan[9] + plan[10] + plan[11] == 16 && plan[3] == 112 && plan[8] == 128);
     }
     const AffinePoint a4 = AffinePoint::from(P4);                                                           // edwards.rs:1071-1092
     CHECK(a4.X * P4.Z == P4.X && a4.Y * P4.Z == P4.Y);
