@@ -702,10 +702,11 @@ def self_launch(args, json_fd):
             raise SystemExit("bench.py: --gpus %d but %d visible device%s: refusing to time fewer GPUs than asked for"
                              % (n, have, "" if have == 1 else "s"))
     # What the ranks inherit can be overridden from the caller's environment (none of it has met a
-    # second GPU yet): MASTER_ADDR / MASTER_PORT when set (default: 127.0.0.1 and a free port), HSA_ENABLE_IPC_MODE_LEGACY when
-    # set (default 0: this image's host driver only supports dmabuf IPC, RCCL's device-memory exchange fails without it).
-    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = os.environ.get("MASTER_PORT")
+    # second GPU yet): ZC_BENCH_MASTER_ADDR / ZC_BENCH_MASTER_PORT (default: 127.0.0.1 and a free port -- a MASTER_PORT left over
+    # in the caller's environment is NOT trusted: it may be taken), HSA_ENABLE_IPC_MODE_LEGACY when set (default 0: this image's
+    # host driver only supports dmabuf IPC, RCCL's device-memory exchange fails without it).
+    addr = os.environ.get("ZC_BENCH_MASTER_ADDR", "127.0.0.1")
+    port = os.environ.get("ZC_BENCH_MASTER_PORT")
     if not port:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))

@@ -162,7 +162,9 @@ def test_plain_python_launch_starts_the_ranks_itself():
     """The driver's observed invocation is plain `python3 bench.py --gpus N ...` (BENCH_r04.json.cmd): with no launcher
     environment bench.py starts the N ranks itself and still prints ONE line with n_gpus = N (one-device test hooks here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(ZC_BENCH_BACKEND="gloo", ZC_BENCH_DEVICE="0")
+    # a rendezvous left over in the caller's environment is not trusted (an unroutable address, a privileged port): the ranks get
+    # 127.0.0.1 and a free port unless ZC_BENCH_MASTER_ADDR / ZC_BENCH_MASTER_PORT say otherwise
+    env.update(ZC_BENCH_BACKEND="gloo", ZC_BENCH_DEVICE="0", MASTER_ADDR="203.0.113.1", MASTER_PORT="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--units", str(1 << 18)],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
