@@ -503,12 +503,15 @@ ZC_KERNEL void k_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
     // edwards.rs:503-531: add of the negated rhs with H = B - a*A == B + A (a = -1): same values
     pt_store_plain(out + 20 * i, pt_add_plain(pt_load_plain(p + 20 * i), pt_neg(pt_load_plain(q + 20 * i))));
 }
+#ifndef ZC_ED_DOUBLE_SQR
+#define ZC_ED_DOUBLE_SQR 1              // Double with the equal-operand products as squarings (0: A/B, pt_add_plain(a, a) as in round 5)
+#endif
 ZC_KERNEL void k_ed_double(const u64* p, u64* out, size_t n)
 {
     const size_t i = gid();
     if (i >= n) return;
     const pt a = pt_load_plain(p + 20 * i);
-    pt_store_plain(out + 20 * i, pt_add_plain(a, a));
+    pt_store_plain(out + 20 * i, ZC_ED_DOUBLE_SQR ? pt_double_plain(a) : pt_add_plain(a, a));
 }
 // The same three with the records staged through LDS (16-byte aligned arrays).  A lane's 160-byte record is strided in
 // memory: read per lane it takes twenty 8-byte loads that each touch a cache line of their own, the wave's working set
@@ -568,7 +571,7 @@ ZC_DI void ed_binop_staged(const u64* p, const u64* q, u64* out, size_t n)
     } else {
         b = a;
     }
-    const pt r = pt_add_plain(a, b);
+    const pt r = OP == 2 && ZC_ED_DOUBLE_SQR ? pt_double_plain(a) : pt_add_plain(a, b);        // (double: four of the products are squarings, same limbs)
     __syncthreads();                                         // ... and then the results
     if (t < cnt) pt_store_plain(sp + 20 * t, r);
     __syncthreads();

@@ -121,7 +121,7 @@ void emul_ed_add_plain(const u64* p, const u64* q, u64* out, size_t n, int mode)
 {
     for (size_t i = 0; i < n; i++) {
         const pt a = pt_load_plain(p + 20 * i), b = pt_load_plain(q + 20 * i);
-        pt_store_plain(out + 20 * i, mode == 0 ? pt_add_plain(a, b) : mode == 1 ? pt_add_plain(a, pt_neg(b)) : pt_add_plain(a, a));
+        pt_store_plain(out + 20 * i, mode == 0 ? pt_add_plain(a, b) : mode == 1 ? pt_add_plain(a, pt_neg(b)) : pt_double_plain(a));     // (mode 2 = k_ed_double: squarings)
     }
 }
 void emul_ed_sub(const u64* p, const u64* q, u64* out, size_t n)
